@@ -1,0 +1,101 @@
+"""ctypes binding of libdlwp_hip.so (the C ABI declared in include/dlwp_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C dlwp_benchmark_amd/csrc`.
+There is NO fallback: if the shared object is missing or a symbol is absent, importing the
+compute path raises -- the product never routes around the HIP kernels.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdlwp_hip.so")
+
+c_float_p = POINTER(c_float)
+c_int32_p = POINTER(c_int32)
+
+
+class FNO2dDesc(ctypes.Structure):
+    """mirror of struct dlwp_fno2d_desc (include/dlwp_hip.h)"""
+    _fields_ = [
+        ("in_channels", c_int32), ("hidden_channels", c_int32), ("lifting_channels", c_int32),
+        ("projection_channels", c_int32), ("out_channels", c_int32), ("n_layers", c_int32),
+        ("height", c_int32), ("width", c_int32), ("n_rows", c_int32), ("n_cols", c_int32),
+        ("rows_in", c_int32_p), ("rows_out", c_int32_p),
+        ("fwd_scale", c_float), ("inv_scale", c_float),
+        ("lift_w1", c_void_p), ("lift_b1", c_void_p), ("lift_w2", c_void_p), ("lift_b2", c_void_p),
+        ("spec_w", POINTER(c_void_p)), ("spec_b", c_void_p), ("skip_w", POINTER(c_void_p)),
+        ("proj_w1", c_void_p), ("proj_b1", c_void_p), ("proj_w2", c_void_p), ("proj_b2", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/dlwp_hip.h declares
+SIGNATURES = {
+    "dlwp_version": (c_int32, []),
+    "dlwp_last_error": (c_char_p, []),
+    "dlwp_device_count": (c_int32, []),
+    "dlwp_fno2d_plan_create": (c_int32, [POINTER(c_void_p), POINTER(FNO2dDesc), c_void_p]),
+    "dlwp_fno2d_plan_destroy": (c_int32, [c_void_p]),
+    "dlwp_fno2d_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "dlwp_fno2d_forward_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "dlwp_fno2d_rollout_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                         c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dlwp_fno2d_dominant_kernel": (c_char_p, []),
+    "dlwp_spectral_conv2d_plan_create": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32,
+                                                   c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "dlwp_spectral_conv2d_plan_destroy": (c_int32, [c_void_p]),
+    "dlwp_spectral_conv2d_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "dlwp_spectral_conv2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+class DlwpError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libdlwp_hip.so and types every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DlwpError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C dlwp_benchmark_amd/csrc`.  There is no CPU fallback for the HIP path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DlwpError(f"libdlwp_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dlwp_last_error().decode(errors="replace")
+        raise DlwpError(f"{what or 'libdlwp_hip'} failed with status {rc}: {msg}")
+
+
+def require_cuda_tensor(t, name: str):
+    import torch
+
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise DlwpError(
+            f"{name} must be a tensor on an MI355X device (got {'cpu tensor' if isinstance(t, torch.Tensor) else type(t)}); "
+            "the HIP path has no CPU fallback -- the CPU restatement lives in oracle/ and is test-only")
+    if t.dtype != torch.float32:
+        raise DlwpError(f"{name} must be float32 (got {t.dtype})")
+
+
+def stream_ptr():
+    import torch
+
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

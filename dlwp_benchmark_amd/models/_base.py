@@ -1,0 +1,44 @@
+"""Shared host-side plumbing for the backbone mirrors.
+
+Every reference backbone has the same boundary:
+  * constructed as `eval(cfg.model.type)(**cfg.model)` (reference scripts/train.py:54,
+    scripts/evaluate.py:140) -> constructors take **kwargs and ignore extras (`type`, `name`);
+  * called by keyword, `model(constants=..., prescribed=..., prognostic=...)`
+    (train.py:263-267, evaluate.py:235-239), returns [B, T-context, Cg, H, W] on the device of
+    `prognostic`;
+  * `.eval()` / `.train()` return the module (the reference Swin returns None,
+    swin_transformer.py:739-742 -- fixed here).
+"""
+import torch
+
+from .. import lib as _lib
+
+
+class HipBackbone(torch.nn.Module):
+    """Base class: input validation + workspace cache.  No CPU path exists by design."""
+
+    def __init__(self):
+        super().__init__()
+        self._ws = None
+
+    def _check_inputs(self, constants, prescribed, prognostic):
+        if prognostic is None:
+            raise _lib.DlwpError("prognostic must be given (reference forward signature)")
+        _lib.require_cuda_tensor(prognostic, "prognostic")
+        _lib.require_cuda_tensor(constants, "constants")
+        _lib.require_cuda_tensor(prescribed, "prescribed")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError(
+                "the MI355X path implements the inference rollout (evaluate.py); training through the "
+                "HIP kernels (backward passes) is not implemented yet -- call .eval() / torch.no_grad()")
+        c = constants.contiguous() if constants is not None else None
+        p = prescribed.contiguous() if prescribed is not None else None
+        return c, p, prognostic.contiguous()
+
+    def _workspace(self, nbytes: int, device) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _param_key(self):
+        return tuple((p._version, p.data_ptr()) for p in self.parameters())

@@ -1,0 +1,72 @@
+"""SpectralConv2d -- drop-in for reference models/unet/unet.py:19-69 (the only in-tree spectral
+convolution; PDE-Arena style) on MI355X.  Same constructor, parameter names (`weights1`,
+`weights2` of shape [Ci, Co, m1, m2, 2]) and forward(x) as the reference class; the forward runs
+`dlwp_spectral_conv2d_f32` (pruned-DFT fp32 MFMA kernels) instead of rfft2 / einsum / irfft2.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import lib as _lib
+
+
+class SpectralConv2d(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, modes1: int, modes2: int):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.modes1 = modes1
+        self.modes2 = modes2
+        self.scale = 1 / (in_channels * out_channels)  # unet.py:38
+        self.weights1 = nn.Parameter(self.scale * torch.rand(in_channels, out_channels, modes1, modes2, 2))
+        self.weights2 = nn.Parameter(self.scale * torch.rand(in_channels, out_channels, modes1, modes2, 2))
+        self._plan = None
+        self._plan_key = None
+        self._ws = None
+
+    def _destroy_plan(self):
+        if self._plan is not None:
+            try:
+                _lib.load().dlwp_spectral_conv2d_plan_destroy(self._plan)
+            except Exception:
+                pass
+            self._plan = None
+
+    def __del__(self):
+        self._destroy_plan()
+
+    def _get_plan(self, h, w, device):
+        key = (h, w, str(device), self.weights1._version, self.weights1.data_ptr(), self.weights2._version,
+               self.weights2.data_ptr())
+        if self._plan is not None and key == self._plan_key:
+            return self._plan
+        self._destroy_plan()
+        lib = _lib.load()
+        w1 = self.weights1.detach().to("cpu", torch.float32).contiguous()
+        w2 = self.weights2.detach().to("cpu", torch.float32).contiguous()
+        plan = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.dlwp_spectral_conv2d_plan_create(
+                ctypes.byref(plan), self.in_channels, self.out_channels, h, w, self.modes1, self.modes2,
+                w1.data_ptr(), w2.data_ptr(), _lib.stream_ptr()), "dlwp_spectral_conv2d_plan_create")
+        self._plan, self._plan_key = plan, key
+        return plan
+
+    @torch.no_grad()
+    def forward(self, x, x_dim=None, y_dim=None):
+        _lib.require_cuda_tensor(x, "x")
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        if c != self.in_channels:
+            raise _lib.DlwpError(f"x has {c} channels, layer expects {self.in_channels}")
+        lib = _lib.load()
+        plan = self._get_plan(h, w, x.device)
+        nbytes = lib.dlwp_spectral_conv2d_workspace_bytes(plan, b)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
+            self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
+        y = torch.empty(b, self.out_channels, h, w, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.dlwp_spectral_conv2d_f32(plan, x.data_ptr(), y.data_ptr(), b, self._ws.data_ptr(), nbytes,
+                                                    _lib.stream_ptr()), "dlwp_spectral_conv2d_f32")
+        return y

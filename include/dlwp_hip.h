@@ -1,0 +1,128 @@
+/*
+ * dlwp_hip.h -- C ABI of libdlwp_hip.so, the MI355X (gfx950) kernel library behind the
+ * dlwpbench backbone rollout hot path.
+ *
+ * The reference (AnneLouisedb/dlwp-benchmark) is pure Python/PyTorch and has no FFI of its own;
+ * every entry point below replaces a stretch of ATen calls inside a reference nn.Module.forward
+ * (cited per function as file:line under src/dlwpbench/).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, explicit sizes, no torch / C++ types.
+ *   - every function returns 0 on success, a negative dlwp_status otherwise; the message for the
+ *     calling thread is available from dlwp_last_error().  No C++ exception crosses the ABI.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     enqueued asynchronously on it; nothing synchronises the device.
+ *   - the caller owns every input / output / workspace buffer; the library owns plan handles.
+ *     Plans are immutable after creation and may be shared between threads.
+ *   - "dev" pointers are device memory, "host" pointers are host memory.
+ */
+#ifndef DLWP_HIP_H
+#define DLWP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dlwp_status {
+  DLWP_OK = 0,
+  DLWP_ERR_INVALID_ARGUMENT = -1,
+  DLWP_ERR_UNSUPPORTED = -2,
+  DLWP_ERR_HIP = -3,
+  DLWP_ERR_WORKSPACE = -4
+} dlwp_status;
+
+/* library version, major*10000 + minor*100 + patch */
+int32_t dlwp_version(void);
+/* message of the last failing call on this thread ("" if none) */
+const char* dlwp_last_error(void);
+/* number of visible HIP devices (<0 on error); does not create a context */
+int32_t dlwp_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * FNO2d rollout  (reference models/fno/fno.py:12-106 `FNO2DModule`; the arithmetic it delegates
+ * to neuralop.models.FNO -- fno.py:38-47 -- is restated in DESIGN.md / oracle/restate/fno.py)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dlwp_fno2d_plan dlwp_fno2d_plan;
+
+typedef struct dlwp_fno2d_desc {
+  int32_t in_channels;         /* constant + (prescribed + prognostic) * context            */
+  int32_t hidden_channels;     /* fno.py:24  (kernel support: 32)                           */
+  int32_t lifting_channels;    /* fno.py:25  (multiple of 16)                               */
+  int32_t projection_channels; /* fno.py:26  (multiple of 16)                               */
+  int32_t out_channels;        /* = prognostic_channels, fno.py:45 (<= 16)                  */
+  int32_t n_layers;            /* fno.py:27                                                 */
+  int32_t height, width;       /* grid; width must be a multiple of 64                      */
+  int32_t n_rows;              /* kept spectral rows   (neuralop: min(H, n_modes[0]))       */
+  int32_t n_cols;              /* kept rfft columns    (neuralop: n_modes[1]/2+1), <= 16    */
+  const int32_t* rows_in;      /* host [n_rows]: un-shifted rfft row read by weight row r   */
+  const int32_t* rows_out;     /* host [n_rows]: un-shifted row of out_fft it lands in      */
+  float fwd_scale;             /* rfftn normalisation  (norm="forward": 1/(H*W))            */
+  float inv_scale;             /* irfftn normalisation (norm="forward": 1)                  */
+  /* weights, HOST pointers, reference (PyTorch) layouts, fp32 */
+  const float* lift_w1;        /* [lifting, in]                                             */
+  const float* lift_b1;        /* [lifting]                                                 */
+  const float* lift_w2;        /* [hidden, lifting]                                         */
+  const float* lift_b2;        /* [hidden]                                                  */
+  const float* const* spec_w;  /* n_layers x [hidden(in), hidden(out), n_rows, n_cols, 2]   */
+  const float* spec_b;         /* [n_layers, hidden]                                        */
+  const float* const* skip_w;  /* n_layers x [hidden(out), hidden(in)]                      */
+  const float* proj_w1;        /* [projection, hidden]                                      */
+  const float* proj_b1;        /* [projection]                                              */
+  const float* proj_w2;        /* [out, projection]                                         */
+  const float* proj_b2;        /* [out]                                                     */
+} dlwp_fno2d_desc;
+
+int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** plan, const dlwp_fno2d_desc* desc, void* stream);
+int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan);
+/* bytes of device workspace one call needs for `batch` samples */
+size_t dlwp_fno2d_workspace_bytes(const dlwp_fno2d_plan* plan, int32_t batch);
+
+/* One backbone step WITHOUT the residual: y = fno(x).  Replaces `self.fno(x_t)` at fno.py:103.
+ * x_dev [B, in, H, W], y_dev [B, out, H, W], both contiguous fp32. */
+int32_t dlwp_fno2d_forward_f32(const dlwp_fno2d_plan* plan, const float* x_dev, float* y_dev,
+                               int32_t batch, void* workspace_dev, size_t workspace_bytes,
+                               void* stream);
+
+/* Whole autoregressive rollout, device resident.  Replaces FNO2DModule.forward, fno.py:64-106
+ * (loop + _prepare_inputs + residual + stack).  Tensors are contiguous fp32:
+ *   constants_dev  [B, 1, Cc, H, W] or NULL (Cc = 0)
+ *   prescribed_dev [B, T, Cp, H, W] or NULL (Cp = 0)
+ *   prognostic_dev [B, T, Cg, H, W]
+ *   out_dev        [B, T - context, Cg, H, W]
+ * with Cc + (Cp + Cg) * context == plan in_channels and Cg == plan out_channels. */
+int32_t dlwp_fno2d_rollout_f32(const dlwp_fno2d_plan* plan, const float* constants_dev,
+                               int32_t n_const, const float* prescribed_dev, int32_t n_presc,
+                               const float* prognostic_dev, int32_t n_prog, int32_t batch,
+                               int32_t n_time, int32_t context, float* out_dev,
+                               void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Profiling aid: name of the dominant device kernel of the FNO step ("" if unknown). */
+const char* dlwp_fno2d_dominant_kernel(void);
+
+/* ------------------------------------------------------------------------------------------
+ * SpectralConv2d  (reference models/unet/unet.py:19-69 + batchmul2d :15-17; PDE-Arena style:
+ * un-normalised rfft2, rows [:m1] with weights1 and rows [-m1:] with weights2, cols [:m2],
+ * irfft2).  x_dev [B, Ci, H, W] -> y_dev [B, Co, H, W], contiguous fp32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dlwp_spectral_plan dlwp_spectral_plan;
+
+int32_t dlwp_spectral_conv2d_plan_create(dlwp_spectral_plan** plan, int32_t in_channels,
+                                         int32_t out_channels, int32_t height, int32_t width,
+                                         int32_t modes1, int32_t modes2,
+                                         const float* weights1_host, /* [Ci,Co,m1,m2,2] */
+                                         const float* weights2_host, /* [Ci,Co,m1,m2,2] */
+                                         void* stream);
+int32_t dlwp_spectral_conv2d_plan_destroy(dlwp_spectral_plan* plan);
+size_t dlwp_spectral_conv2d_workspace_bytes(const dlwp_spectral_plan* plan, int32_t batch);
+int32_t dlwp_spectral_conv2d_f32(const dlwp_spectral_plan* plan, const float* x_dev, float* y_dev,
+                                 int32_t batch, void* workspace_dev, size_t workspace_bytes,
+                                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLWP_HIP_H */

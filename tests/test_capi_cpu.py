@@ -1,0 +1,53 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/dlwp_hip.h
+declares, and the product path fails loudly without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from dlwp_benchmark_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dlwp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dlwp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = L.load()
+    declared = _declared_symbols()
+    assert declared, "no symbols parsed from include/dlwp_hip.h"
+    for name in declared:
+        assert hasattr(lib, name), f"libdlwp_hip.so does not export {name}"
+    # the ctypes table covers the header exactly
+    assert sorted(L.SIGNATURES) == declared
+    assert lib.dlwp_version() >= 100
+
+
+def test_error_reporting_without_gpu():
+    lib = L.load()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.dlwp_device_count() < 0
+    assert b"hipGetDeviceCount" in lib.dlwp_last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    from dlwp_benchmark_amd.models import FNO2DModule
+
+    m = FNO2DModule(constant_channels=0, prescribed_channels=0, prognostic_channels=1, context_size=1).eval()
+    with pytest.raises(L.DlwpError, match="no CPU fallback"):
+        m(prognostic=torch.zeros(1, 3, 1, 64, 64))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "dlwp_benchmark_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports oracle"

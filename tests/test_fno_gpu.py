@@ -1,0 +1,150 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): HIP path (through the C ABI) vs the
+oracle (CPU restatement, oracle/restate/fno.py) and vs the reference-generated golden fixtures.
+
+Tolerance (BASELINE.json north_star): per-step relative L2 <= 1e-5 in fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import fno_std_fn, load_golden, per_step_rel_l2, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ SpectralConv2d (pinned)
+@pytest.mark.parametrize("tag,shape", [
+    ("c32_64x64_m12", (32, 32, 64, 64, 12, 12, 1)),
+    ("c32_32x64_m8x6", (32, 32, 32, 64, 8, 6, 1)),
+])
+def test_spectral_conv2d_matches_reference_golden(tag, shape):
+    from dlwp_benchmark_amd.models.spectral import SpectralConv2d
+    from oracle.make_golden import spectral_conv2d_case
+
+    ci, co, h, w, m1, m2, b = shape
+    g = load_golden(f"spectral_conv2d_{tag}")
+    x, w1, w2 = spectral_conv2d_case(ci, co, h, w, m1, m2, b, tag)
+    mod = SpectralConv2d(ci, co, m1, m2)
+    with torch.no_grad():
+        mod.weights1.copy_(w1)
+        mod.weights2.copy_(w2)
+    mod = mod.to(_dev())
+    y = mod(x.to(_dev()))
+    torch.cuda.synchronize()
+    err = rel_l2(y, torch.from_numpy(g["y"]))
+    assert err <= TOL, f"rel L2 {err:.3e}"
+
+
+def test_spectral_conv2d_batch_and_linearity():
+    """size-independent properties at the full batch: linearity in x and batch independence."""
+    from dlwp_benchmark_amd.models.spectral import SpectralConv2d
+    from oracle.restate.fno import spectral_conv2d_ref
+
+    torch.manual_seed(3)
+    mod = SpectralConv2d(32, 32, 12, 12).to(_dev())
+    x1 = torch.randn(32, 32, 64, 64, device=_dev())
+    x2 = torch.randn(32, 32, 64, 64, device=_dev())
+    y1, y2, y12 = mod(x1), mod(x2), mod(2.0 * x1 - 0.5 * x2)
+    assert rel_l2(y12, 2.0 * y1 - 0.5 * y2) < 5e-6
+    ys = mod(x1[5:7].contiguous())
+    assert torch.equal(ys, y1[5:7])
+    ref = spectral_conv2d_ref(x1[:2].cpu(), mod.weights1.detach().cpu(), mod.weights2.detach().cpu())
+    assert rel_l2(y1[:2], ref) <= TOL
+
+
+# ------------------------------------------------------------------ FNO2DModule (restated; parity unpinned)
+def _make_pair(gain=0.85, **kw):
+    from dlwp_benchmark_amd.models import FNO2DModule
+    from dlwp_benchmark_amd.weights import fill_state_dict
+    from oracle.restate.fno import FNO2DModuleRef
+
+    ref = FNO2DModuleRef(**kw).eval()
+    fill_state_dict(ref, std_fn=fno_std_fn(gain), gain=gain)
+    hip = FNO2DModule(**kw)
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip.to(_dev()).eval()
+
+
+NS_KW = dict(n_modes=[12, 12], constant_channels=0, prescribed_channels=0, prognostic_channels=1,
+             hidden_channels=32, lifting_channels=256, projection_channels=256, n_layers=4, context_size=1)
+
+
+def test_fno_one_step_increment():
+    """the backbone increment f(x_t) itself (no residual hiding errors)."""
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    ref, hip = _make_pair(**NS_KW)
+    _, _, prog = navier_stokes(4, 1)
+    x = prog[:, 0]
+    with torch.no_grad():
+        want = ref.fno(x)
+    got = hip.one_step(x.to(_dev()))
+    torch.cuda.synchronize()
+    err = rel_l2(got, want)
+    assert err <= TOL, f"rel L2 of increment {err:.3e}"
+
+
+def test_fno_rollout_20_steps_ns64():
+    """BASELINE config C2 at a batch the oracle finishes in seconds."""
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    ref, hip = _make_pair(**NS_KW)
+    _, _, prog = navier_stokes(2, 21)
+    with torch.no_grad():
+        want = ref(prognostic=prog)
+    got = hip(prognostic=prog.to(_dev()))
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (2, 20, 1, 64, 64)
+    errs = per_step_rel_l2(got, want)
+    assert max(errs) <= TOL, f"per-step rel L2 {['%.2e' % e for e in errs]}"
+
+
+def test_fno_rollout_context_constants_prescribed():
+    """context_size > 1 with constants and prescribed: exercises the channel-segment table
+    that replaces _prepare_inputs / the window blending of fno.py:79-100."""
+    from dlwp_benchmark_amd.synthetic import weatherbench
+
+    kw = dict(NS_KW, constant_channels=4, prescribed_channels=1, prognostic_channels=2, context_size=2)
+    ref, hip = _make_pair(gain=0.7, **kw)
+    cons, presc, prog = weatherbench(2, 7, 32, 64, prognostic_channels=2)
+    with torch.no_grad():
+        want = ref(constants=cons, prescribed=presc, prognostic=prog)
+    d = _dev()
+    got = hip(constants=cons.to(d), prescribed=presc.to(d), prognostic=prog.to(d))
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (2, 5, 2, 32, 64)
+    errs = per_step_rel_l2(got, want)
+    assert max(errs) <= TOL, f"per-step rel L2 {['%.2e' % e for e in errs]}"
+
+
+def test_fno_full_batch_properties():
+    """B=32 (the benchmark batch): batch independence + determinism, checked without the oracle."""
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    _, hip = _make_pair(**NS_KW)
+    _, _, prog = navier_stokes(32, 6)
+    p = prog.to(_dev())
+    a = hip(prognostic=p)
+    b = hip(prognostic=p)
+    assert torch.equal(a, b)
+    sub = hip(prognostic=p[7:9].contiguous())
+    assert torch.equal(sub, a[7:9])
+    assert torch.isfinite(a).all()
+
+
+def test_fno_argument_errors():
+    from dlwp_benchmark_amd import lib as L
+
+    _, hip = _make_pair(**NS_KW)
+    with pytest.raises(L.DlwpError):
+        hip(prognostic=torch.zeros(1, 1, 1, 64, 64, device=_dev()))      # T <= context
+    with pytest.raises(L.DlwpError):
+        hip(prognostic=torch.zeros(1, 3, 2, 64, 64, device=_dev()))      # wrong channel count
+    with pytest.raises(L.DlwpError):
+        hip(prognostic=torch.zeros(1, 3, 1, 64, 48, device=_dev()))      # unsupported width
