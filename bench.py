@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Headline benchmark: autoregressive rollout throughput of the FNO2d backbone on MI355X.
+
+Workload (BASELINE.json configs[1]): FNO2d modes=12, hidden 32, lifting/projection 256, 4 layers
+on synthetic Navier-Stokes 64x64, batch 32 (reference configs/testing/default.yaml:1), 20-step
+rollout, fp32.  One bench "step" = one whole 20-step rollout of the batch; inputs are resident in
+HBM before the timed region.  Metric: grid-cells x rollout-steps per second, whole job.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: every rank rolls out its own shard of initial conditions (weak scaling, no collective in
+the step); the trajectories are collected with ONE RCCL all-gather per rollout (issued in time
+chunks on RCCL's stream so it overlaps the remaining rollout steps).
+
+Extra legs in the same run (rank 0, N = 1 only):
+  roofline      per-kernel HIP-event timing of the same rollout (dlwp_fno2d_rollout_profiled_f32)
+  cpu_baseline  the oracle (PyTorch CPU restatement of the reference forward) timed on the host
+                cores on a bounded sample; also yields the per-step rel-L2 of the HIP trajectory.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3    # same guide: fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+
+MODEL_KW = dict(n_modes=[12, 12], constant_channels=0, prescribed_channels=0, prognostic_channels=1,
+                hidden_channels=32, lifting_channels=256, projection_channels=256, n_layers=4, context_size=1)
+
+
+def std_fn(name, shape):
+    if "convs.weight" in name:
+        return 0.85 / shape[0] ** 0.5
+    return None
+
+
+def build_model(device):
+    from dlwp_benchmark_amd.models import FNO2DModule
+    from dlwp_benchmark_amd.weights import fill_state_dict
+
+    m = FNO2DModule(**MODEL_KW)
+    sha = fill_state_dict(m, std_fn=std_fn, gain=0.85)
+    return m.to(device).eval(), sha
+
+
+def algorithmic_work(B, H, W, kw, n_rows, n_cols):
+    """Per-LAUNCH algorithmic bytes / flops of each kernel class."""
+    P = B * H * W
+    ch, cl, cp = kw["hidden_channels"], kw["lifting_channels"], kw["projection_channels"]
+    cin = kw["constant_channels"] + (kw["prescribed_channels"] + kw["prognostic_channels"]) * kw["context_size"]
+    cout = kw["prognostic_channels"]
+    return {
+        "lift": {"bytes": 4 * P * (cin + ch) + 4 * (cl * cin + cl + ch * cl + ch),
+                 "flops": 2 * P * (cin * cl + cl * ch)},
+        "modes": {"bytes": 8 * ch * ch * n_rows * n_cols, "flops": 8 * B * ch * ch * n_rows * n_cols},
+        "layer": {"bytes": 4 * P * 2 * ch + 4 * ch * ch,
+                  "flops": 2 * P * ch * ch + 2 * 2 * P * ch * 2 * n_cols},
+        "proj": {"bytes": 4 * P * (ch + 2 * cout) + 4 * (cp * ch + cp + cout * cp + cout),
+                 "flops": 2 * P * (ch * cp + cp * cout)},
+    }
+
+
+def profile_kernels(model, prog, repeats):
+    """Runs the rollout with per-launch HIP event brackets; returns {class: (avg_ms, launches)}."""
+    from dlwp_benchmark_amd import lib as L
+
+    lib = L.load()
+    b, t, cg, h, w = prog.shape
+    plan = model._get_plan(h, w, prog.device)
+    out = torch.empty(b, t - model.context_size, cg, h, w, device=prog.device)
+    nbytes = lib.dlwp_fno2d_workspace_bytes(plan, b)
+    ws = model._workspace(nbytes, prog.device)
+    ms = (ctypes.c_double * 4)()
+    cnt = (ctypes.c_int32 * 4)()
+    tot = [0.0] * 4
+    n = [0] * 4
+    for _ in range(repeats):
+        L.check(lib.dlwp_fno2d_rollout_profiled_f32(plan, None, 0, None, 0, prog.data_ptr(), cg, b, t,
+                                                    model.context_size, out.data_ptr(), ws.data_ptr(), nbytes,
+                                                    L.stream_ptr(), ms, cnt), "profiled rollout")
+        for i in range(4):
+            tot[i] += ms[i]
+            n[i] += cnt[i]
+    names = ["lift", "modes", "layer", "proj"]
+    return {names[i]: (tot[i] / max(n[i], 1), n[i] // repeats) for i in range(4)}
+
+
+def cpu_baseline(state_dict, prog_cpu, rollout_steps):
+    """Times the oracle on the host cores; returns (cell-steps/s, seconds, trajectory)."""
+    from oracle.restate.fno import FNO2DModuleRef  # checker / reported baseline only
+
+    ref = FNO2DModuleRef(**MODEL_KW).eval()
+    ref.load_state_dict(state_dict)
+    with torch.no_grad():
+        ref(prognostic=prog_cpu[:, :2])  # warm-up: one step
+        t0 = time.perf_counter()
+        traj = ref(prognostic=prog_cpu)
+        dt = time.perf_counter() - t0
+    b, _, _, h, w = prog_cpu.shape
+    return b * h * w * rollout_steps / dt, dt, traj
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="initial conditions per GPU")
+    ap.add_argument("--rollout-steps", type=int, default=20)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="samples of the bounded CPU-baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-chunks", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from dlwp_benchmark_amd.sharding import ShardedRollout
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    B, K_roll, H, W = args.batch, args.rollout_steps, 64, 64
+    model, sha = build_model(device)
+    _, _, prog_cpu = navier_stokes(B, K_roll + 1, H, W, seed=1234 + rank)
+    prog = prog_cpu.to(device)
+    runner = ShardedRollout(model, world_size=world, rank=rank, chunks=args.gather_chunks)
+
+    def step():
+        return runner(prognostic=prog)
+
+    for _ in range(args.warmup):
+        out = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * H * W * K_roll * args.steps / dt
+
+    result = {
+        "metric": "rollout cell-steps/s",
+        "value": value,
+        "unit": "grid-cells*steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "FNO2d modes=12 hidden=32 lift/proj=256 layers=4, Navier-Stokes 64x64, 20-step rollout, fp32 (BASELINE configs[1])",
+            "batch_per_gpu": B, "global_batch": B * world, "grid": [H, W], "rollout_steps": K_roll,
+            "parallelism": f"batch-shard x{world} + all-gather" if world > 1 else "single GPU",
+            "weights": "deterministic filler sha256:" + sha[:16],
+        },
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline leg: per-kernel HIP-event timing of the same rollout
+        prof = profile_kernels(model, prog, repeats=max(2, min(args.steps, 5)))
+        rows_in = 12
+        work = algorithmic_work(B, H, W, MODEL_KW, rows_in, MODEL_KW["n_modes"][1] // 2 + 1)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))
+            except Exception:
+                traffic = None
+        per_kernel = {}
+        for name, (avg_ms, launches) in prof.items():
+            w_ = work[name]
+            per_kernel[name] = {
+                "avg_ms": avg_ms, "launches_per_rollout": launches,
+                "GBps": w_["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
+                "TFLOPs": w_["flops"] / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None,
+                "share_of_rollout": avg_ms * launches / ms_per_step,
+            }
+        # the kernel the north star names (spectral-conv layer, HBM-bound)
+        lay = per_kernel["layer"]
+        result["roofline"] = {
+            "kernel": "fno_layer_kernel", "bound": "hbm", "achieved": lay["GBps"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": lay["GBps"] / HBM_PEAK_GBS if lay["GBps"] else None,
+            "traffic": (traffic or {}).get("fno_layer_kernel"),
+            "algorithmic_bytes_per_launch": work["layer"]["bytes"], "avg_launch_ms": lay["avg_ms"],
+        }
+        # the two MFMA-bound MLP kernels, priced against the fp32 matrix peak
+        for nm in ("lift", "proj"):
+            k = per_kernel[nm]
+            k["frac_mfma_f32_peak"] = k["TFLOPs"] / MFMA_F32_PEAK_TF if k["TFLOPs"] else None
+        result["kernels"] = per_kernel
+
+        # ---- CPU baseline leg (oracle on the host cores) + per-step rel-L2
+        if not args.no_cpu_baseline:
+            nb = min(args.cpu_batch, B)
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            cps, secs, traj = cpu_baseline(sd, prog_cpu[:nb].contiguous(), K_roll)
+            got = out[:nb].detach().cpu().double()
+            want = traj.double()
+            errs = [float(torch.linalg.vector_norm(got[:, t] - want[:, t]) / torch.linalg.vector_norm(want[:, t]))
+                    for t in range(K_roll)]
+            result["cpu_baseline"] = {
+                "value": cps, "unit": "grid-cells*steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"oracle (PyTorch {torch.__version__} CPU restatement) on {nb} of the {B} initial conditions, "
+                          f"{K_roll} steps, {secs:.2f} s",
+            }
+            result["rel_l2_per_step_max"] = max(errs)
+            result["rel_l2_per_step"] = [float(f"{e:.3e}") for e in errs]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

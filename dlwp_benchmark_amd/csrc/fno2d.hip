@@ -662,6 +662,24 @@ extern "C" int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan) {
 }
 
 namespace {
+// Optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
+struct KernelTimer {
+  enum { LIFT = 0, MODES = 1, LAYER = 2, PROJ = 3, NCLASS = 4 };
+  std::vector<hipEvent_t> ev[NCLASS];  // start/stop pairs
+  hipStream_t s = nullptr;
+  hipError_t begin(int cls) {
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return rc;
+    ev[cls].push_back(e);
+    return hipEventRecord(e, s);
+  }
+  hipError_t end(int cls) { return begin(cls); }
+  ~KernelTimer() {
+    for (auto& v : ev)
+      for (auto e : v) (void)hipEventDestroy(e);
+  }
+};
 struct FnoWorkspace {
   float *h0, *h1, *ybuf, *zbuf;
   size_t total;
@@ -694,7 +712,8 @@ int32_t launch_lift_cs(const MlpParams& mp, int kp, int grid, size_t lds, hipStr
 
 // one backbone step: x (channel table) -> out (+ resid)
 int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const FnoWorkspace& ws, float* out,
-                 long long out_bstride, const float* resid, long long resid_bstride, hipStream_t s) {
+                 long long out_bstride, const float* resid, long long resid_bstride, hipStream_t s,
+                 KernelTimer* timer = nullptr) {
   const int nrow = B * p->H;
   // lifting (+ W-direction DFT of its output)
   {
@@ -710,6 +729,7 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     const size_t lds = ((size_t)nt * p->cin_steps * 64 + p->hid_l + (size_t)nt * 4 * 2 * 64 + 4 * kC * kTrStride) * 4;
     const int grid = grid_rows(nrow, 4);
     int32_t rc;
+    if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::LIFT));
     switch (p->cin_steps) {
       case 1: rc = launch_lift_cs<1>(mp, p->sc.KP, grid, lds, s); break;
       case 2: rc = launch_lift_cs<2>(mp, p->sc.KP, grid, lds, s); break;
@@ -721,20 +741,25 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
       default: rc = launch_lift_cs<8>(mp, p->sc.KP, grid, lds, s); break;
     }
     if (rc != DLWP_OK) return rc;
+    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::LIFT));
   }
   float* hin = ws.h0;
   float* hout = ws.h1;
   for (int l = 0; l < p->L; ++l) {
+    if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::MODES));
     int32_t rc = launch_modes(p->sc, ws.ybuf, ws.zbuf, p->wt[l].as<float2>(), B, s);
     if (rc != DLWP_OK) return rc;
+    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::MODES));
     LayerParams lp;
     lp.x = hin; lp.y = hout; lp.wsp = p->wsp[l].as<float>(); lp.bias = p->sbias[l].as<float>();
     lp.zbuf = ws.zbuf; lp.t = p->sc.t.as<float>(); lp.tt = p->sc.tt.as<float>(); lp.ybuf = ws.ybuf;
     lp.B = B; lp.H = p->H; lp.W = p->W;
     const bool last = (l == p->L - 1);
     // neuralop FNOBlocks.forward_with_postactivation: GELU after every layer but the last
+    if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::LAYER));
     rc = last ? launch_layer<true, false, false>(p->sc, lp, s) : launch_layer<true, true, true>(p->sc, lp, s);
     if (rc != DLWP_OK) return rc;
+    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::LAYER));
     float* t = hin; hin = hout; hout = t;
   }
   // projection (+ residual)
@@ -751,6 +776,7 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     const int nt = p->hid_p / 16;
     const size_t lds = ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * 4 * 1 * 64) * 4;
     const int grid = grid_rows(nrow, 4);
+    if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::PROJ));
     if (resid) {
       DLWP_HIP_CHECK(allow_lds(pw_mlp2_kernel<8, 1, 16, false, true>, lds));
       hipLaunchKernelGGL((pw_mlp2_kernel<8, 1, 16, false, true>), dim3(grid), dim3(256), lds, s, mp);
@@ -759,6 +785,7 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
       hipLaunchKernelGGL((pw_mlp2_kernel<8, 1, 16, false, false>), dim3(grid), dim3(256), lds, s, mp);
     }
     DLWP_HIP_CHECK(hipGetLastError());
+    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::PROJ));
   }
   return DLWP_OK;
 }
@@ -785,10 +812,11 @@ extern "C" int32_t dlwp_fno2d_forward_f32(const dlwp_fno2d_plan* plan, const flo
   return fno_step(plan, xt, batch, ws, y, plan->cout * HW, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int32_t dlwp_fno2d_rollout_f32(const dlwp_fno2d_plan* plan, const float* constants, int32_t n_const,
-                                          const float* prescribed, int32_t n_presc, const float* prognostic,
-                                          int32_t n_prog, int32_t batch, int32_t n_time, int32_t context, float* out,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
+static int32_t fno_rollout_impl(const dlwp_fno2d_plan* plan, const float* constants, int32_t n_const,
+                                const float* prescribed, int32_t n_presc, const float* prognostic,
+                                int32_t n_prog, int32_t batch, int32_t n_time, int32_t context, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream, KernelTimer* timer,
+                                int32_t step_begin = 0, int32_t step_end = -1) {
   DLWP_REQUIRE(plan && prognostic && out && workspace, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0 && context >= 1 && n_time > context, DLWP_ERR_INVALID_ARGUMENT,
                "need batch > 0, context >= 1, n_time > context (got %d, %d, %d)", batch, context, n_time);
@@ -808,7 +836,10 @@ extern "C" int32_t dlwp_fno2d_rollout_f32(const dlwp_fno2d_plan* plan, const flo
   const long long HW = (long long)plan->H * plan->W;
   const int T = n_time, ctx = context, To = T - ctx;
   const long long prog_bs = (long long)T * n_prog * HW, out_bs = (long long)To * n_prog * HW;
-  for (int t = ctx; t < T; ++t) {
+  if (step_end < 0) step_end = To;
+  DLWP_REQUIRE(step_begin >= 0 && step_begin <= step_end && step_end <= To, DLWP_ERR_INVALID_ARGUMENT,
+               "step range [%d, %d) outside [0, %d]", step_begin, step_end, To);
+  for (int t = ctx + step_begin; t < ctx + step_end; ++t) {
     // x_t = cat(constants[:,0], prescribed[:, t-ctx:t], prognostic window)   (fno.py:49-62, :79-100)
     // prognostic window, frame f in [t-ctx, t): input frame f if f < ctx else out[:, f-ctx]
     ChanTable xt;
@@ -828,13 +859,57 @@ extern "C" int32_t dlwp_fno2d_rollout_f32(const dlwp_fno2d_plan* plan, const flo
     long long resid_bs;
     if (t - 1 < ctx) { resid = prognostic + (long long)(t - 1) * n_prog * HW; resid_bs = prog_bs; }
     else { resid = out + (long long)(t - 1 - ctx) * n_prog * HW; resid_bs = out_bs; }
-    int32_t rc = fno_step(plan, xt, batch, ws, out + (long long)(t - ctx) * n_prog * HW, out_bs, resid, resid_bs, s);
+    int32_t rc = fno_step(plan, xt, batch, ws, out + (long long)(t - ctx) * n_prog * HW, out_bs, resid, resid_bs, s, timer);
     if (rc != DLWP_OK) return rc;
   }
   return DLWP_OK;
 }
 
-extern "C" const char* dlwp_fno2d_dominant_kernel(void) { return "fno_layer_kernel"; }
+extern "C" int32_t dlwp_fno2d_rollout_f32(const dlwp_fno2d_plan* plan, const float* constants, int32_t n_const,
+                                          const float* prescribed, int32_t n_presc, const float* prognostic,
+                                          int32_t n_prog, int32_t batch, int32_t n_time, int32_t context, float* out,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  return fno_rollout_impl(plan, constants, n_const, prescribed, n_presc, prognostic, n_prog, batch, n_time, context,
+                          out, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int32_t dlwp_fno2d_rollout_range_f32(const dlwp_fno2d_plan* plan, const float* constants, int32_t n_const,
+                                                const float* prescribed, int32_t n_presc, const float* prognostic,
+                                                int32_t n_prog, int32_t batch, int32_t n_time, int32_t context,
+                                                float* out, void* workspace, size_t workspace_bytes, void* stream,
+                                                int32_t step_begin, int32_t step_end) {
+  return fno_rollout_impl(plan, constants, n_const, prescribed, n_presc, prognostic, n_prog, batch, n_time, context,
+                          out, workspace, workspace_bytes, stream, nullptr, step_begin, step_end);
+}
+
+extern "C" int32_t dlwp_fno2d_rollout_profiled_f32(const dlwp_fno2d_plan* plan, const float* constants,
+                                                   int32_t n_const, const float* prescribed, int32_t n_presc,
+                                                   const float* prognostic, int32_t n_prog, int32_t batch,
+                                                   int32_t n_time, int32_t context, float* out, void* workspace,
+                                                   size_t workspace_bytes, void* stream, double* class_ms,
+                                                   int32_t* class_launches) {
+  DLWP_REQUIRE(class_ms && class_launches, DLWP_ERR_INVALID_ARGUMENT, "null profile output");
+  KernelTimer timer;
+  timer.s = reinterpret_cast<hipStream_t>(stream);
+  int32_t rc = fno_rollout_impl(plan, constants, n_const, prescribed, n_presc, prognostic, n_prog, batch, n_time,
+                                context, out, workspace, workspace_bytes, stream, &timer);
+  if (rc != DLWP_OK) return rc;
+  DLWP_HIP_CHECK(hipStreamSynchronize(timer.s));
+  for (int c = 0; c < KernelTimer::NCLASS; ++c) {
+    double tot = 0.0;
+    const size_t n = timer.ev[c].size() / 2;
+    for (size_t i = 0; i < n; ++i) {
+      float ms = 0.f;
+      DLWP_HIP_CHECK(hipEventElapsedTime(&ms, timer.ev[c][2 * i], timer.ev[c][2 * i + 1]));
+      tot += ms;
+    }
+    class_ms[c] = tot;
+    class_launches[c] = (int32_t)n;
+  }
+  return DLWP_OK;
+}
+
+
 
 // ---------------------------------------------------------------------------------------------
 // SpectralConv2d (unet.py:19-69)

@@ -40,7 +40,12 @@ SIGNATURES = {
     "dlwp_fno2d_forward_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "dlwp_fno2d_rollout_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                                          c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dlwp_fno2d_dominant_kernel": (c_char_p, []),
+    "dlwp_fno2d_rollout_range_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                               c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p,
+                                               c_int32, c_int32]),
+    "dlwp_fno2d_rollout_profiled_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                                  c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p,
+                                                  POINTER(ctypes.c_double), c_int32_p]),
     "dlwp_spectral_conv2d_plan_create": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32,
                                                    c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "dlwp_spectral_conv2d_plan_destroy": (c_int32, [c_void_p]),

@@ -175,6 +175,26 @@ class FNO2DModule(HipBackbone):
                                                   _lib.stream_ptr()), "dlwp_fno2d_forward_f32")
         return y
 
+    def rollout_into(self, out: torch.Tensor, constants, prescribed, prognostic, step_begin: int = 0,
+                     step_end: int = -1) -> torch.Tensor:
+        """Runs rollout steps [step_begin, step_end) into `out` [B, T-ctx, Cg, H, W] (earlier steps
+        must already be there).  Inputs are validated, contiguous CUDA tensors."""
+        b, t, cg, h, w = prognostic.shape
+        ctx = self.context_size
+        cc = constants.shape[2] if constants is not None else 0
+        cp = prescribed.shape[2] if prescribed is not None else 0
+        lib = _lib.load()
+        plan = self._get_plan(h, w, prognostic.device)
+        nbytes = lib.dlwp_fno2d_workspace_bytes(plan, b)
+        ws = self._workspace(nbytes, prognostic.device)
+        with torch.cuda.device(prognostic.device):
+            _lib.check(lib.dlwp_fno2d_rollout_range_f32(
+                plan, constants.data_ptr() if constants is not None else None, cc,
+                prescribed.data_ptr() if prescribed is not None else None, cp,
+                prognostic.data_ptr(), cg, b, t, ctx, out.data_ptr(), ws.data_ptr(), nbytes,
+                _lib.stream_ptr(), step_begin, step_end), "dlwp_fno2d_rollout_range_f32")
+        return out
+
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
         constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
@@ -183,17 +203,6 @@ class FNO2DModule(HipBackbone):
             ctx = self.context_size
             if t <= ctx:
                 raise _lib.DlwpError(f"need more than context_size={ctx} frames, got {t}")
-            cc = constants.shape[2] if constants is not None else 0
-            cp = prescribed.shape[2] if prescribed is not None else 0
-            lib = _lib.load()
-            plan = self._get_plan(h, w, prognostic.device)
             out = torch.empty(b, t - ctx, cg, h, w, device=prognostic.device, dtype=torch.float32)
-            nbytes = lib.dlwp_fno2d_workspace_bytes(plan, b)
-            ws = self._workspace(nbytes, prognostic.device)
-            with torch.cuda.device(prognostic.device):
-                _lib.check(lib.dlwp_fno2d_rollout_f32(
-                    plan, constants.data_ptr() if constants is not None else None, cc,
-                    prescribed.data_ptr() if prescribed is not None else None, cp,
-                    prognostic.data_ptr(), cg, b, t, ctx, out.data_ptr(), ws.data_ptr(), nbytes,
-                    _lib.stream_ptr()), "dlwp_fno2d_rollout_f32")
+            self.rollout_into(out, constants, prescribed, prognostic)
         return out

@@ -1,0 +1,78 @@
+"""Multi-GPU rollout: shard the batch of initial conditions, one process per GPU.
+
+The reference is single-process / single-device (no DDP, no collectives
+on the live path).  Rollouts of different initial conditions are independent (no cross-sample op
+in any backbone in eval mode), so the path shards with NO collective inside the step; the only
+exchange is collecting the trajectories ([B/N, K, Cg, H, W] per rank) for the evaluation metrics
+(reference scripts/evaluate.py:243 `outputs.append(output.cpu())`): ONE all-gather per rollout
+over RCCL/xGMI.  It is issued per time chunk with async_op=True -- ProcessGroupNCCL runs it on its
+own HIP stream after the chunk's kernels -- so the transfer of chunk k overlaps the compute of
+chunk k+1 and only the last chunk's gather is exposed.
+
+Works with any process group backend (`gloo` in the CPU tests); with world_size == 1 it is the
+plain device-resident rollout.
+"""
+from typing import Optional
+
+import torch
+
+
+def shard_bounds(n_items: int, world_size: int, rank: int):
+    """Contiguous split of `n_items` initial conditions: rank r gets [lo, hi)."""
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def chunk_bounds(n_steps: int, chunks: int, min_len: int = 1):
+    chunks = max(1, min(chunks, n_steps // max(min_len, 1) or 1))
+    base, rem = divmod(n_steps, chunks)
+    out, a = [], 0
+    for c in range(chunks):
+        b = a + base + (1 if c < rem else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
+class ShardedRollout:
+    """Callable: runs `model`'s rollout on this rank's shard and returns the gathered global
+    trajectory [world*B_local, K, Cg, H, W] (rank-major).  `model` must provide
+    `rollout_into(out, constants, prescribed, prognostic, step_begin, step_end)`, `_check_inputs`
+    and `context_size` (every dlwp_benchmark_amd backbone does)."""
+
+    def __init__(self, model, world_size: int = 1, rank: int = 0, chunks: int = 4, group=None):
+        self.model = model
+        self.world = world_size
+        self.rank = rank
+        self.chunks = chunks
+        self.group = group
+
+    def __call__(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
+                 prognostic: torch.Tensor = None) -> torch.Tensor:
+        m = self.model
+        constants, prescribed, prognostic = m._check_inputs(constants, prescribed, prognostic)
+        b, t, cg, h, w = prognostic.shape
+        ctx = m.context_size
+        k = t - ctx
+        with torch.no_grad():
+            local = torch.empty(b, k, cg, h, w, device=prognostic.device, dtype=prognostic.dtype)
+            if self.world == 1:
+                m.rollout_into(local, constants, prescribed, prognostic, 0, k)
+                return local
+            import torch.distributed as dist
+
+            bounds = chunk_bounds(k, self.chunks)
+            works, parts = [], []
+            for (a, e) in bounds:
+                m.rollout_into(local, constants, prescribed, prognostic, a, e)
+                send = local[:, a:e].contiguous()
+                recv = torch.empty((self.world * b,) + tuple(send.shape[1:]), device=send.device, dtype=send.dtype)
+                works.append(dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True))
+                parts.append((send, recv))
+            out = torch.empty(self.world * b, k, cg, h, w, device=prognostic.device, dtype=prognostic.dtype)
+            ov = out.view(self.world, b, k, cg, h, w)
+            for (a, e), wk, (_, recv) in zip(bounds, works, parts):
+                wk.wait()
+                ov[:, :, a:e].copy_(recv.view(self.world, b, e - a, cg, h, w))
+            return out

@@ -100,8 +100,28 @@ int32_t dlwp_fno2d_rollout_f32(const dlwp_fno2d_plan* plan, const float* constan
                                int32_t n_time, int32_t context, float* out_dev,
                                void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Profiling aid: name of the dominant device kernel of the FNO step ("" if unknown). */
-const char* dlwp_fno2d_dominant_kernel(void);
+/* Rollout steps [step_begin, step_end) only (0 <= begin <= end <= T - context); steps before
+ * step_begin must already be present in out_dev.  Lets the host overlap the all-gather of finished
+ * time chunks with the remaining steps (dlwp_benchmark_amd/sharding.py). */
+int32_t dlwp_fno2d_rollout_range_f32(const dlwp_fno2d_plan* plan, const float* constants_dev,
+                                     int32_t n_const, const float* prescribed_dev, int32_t n_presc,
+                                     const float* prognostic_dev, int32_t n_prog, int32_t batch,
+                                     int32_t n_time, int32_t context, float* out_dev,
+                                     void* workspace_dev, size_t workspace_bytes, void* stream,
+                                     int32_t step_begin, int32_t step_end);
+
+/* Same rollout with every kernel launch bracketed by a pair of HIP events on `stream`
+ * (measurement aid for bench.py's roofline leg; synchronises the stream before returning).
+ * Kernel classes: 0 lifting MLP (pw_mlp2_kernel<..,EMIT_Y>), 1 fno_modes_kernel,
+ * 2 fno_layer_kernel, 3 projection MLP (pw_mlp2_kernel<..,RESID>).
+ * class_ms[4]: summed event-to-event milliseconds, class_launches[4]: launches per class. */
+int32_t dlwp_fno2d_rollout_profiled_f32(const dlwp_fno2d_plan* plan, const float* constants_dev,
+                                        int32_t n_const, const float* prescribed_dev,
+                                        int32_t n_presc, const float* prognostic_dev,
+                                        int32_t n_prog, int32_t batch, int32_t n_time,
+                                        int32_t context, float* out_dev, void* workspace_dev,
+                                        size_t workspace_bytes, void* stream, double* class_ms,
+                                        int32_t* class_launches);
 
 /* ------------------------------------------------------------------------------------------
  * SpectralConv2d  (reference models/unet/unet.py:19-69 + batchmul2d :15-17; PDE-Arena style:
