@@ -78,6 +78,7 @@ __device__ __forceinline__ void fwd_dft_accumulate(const float* s_tr, const floa
   }
 }
 
+// Y layout [B][H][KP][C] (c fastest): one 16-byte store per (ct, kt) per lane.
 template <int NT, int KP>
 __device__ __forceinline__ void store_y(float* __restrict__ ybuf, long long row, int nchan, int lane,
                                         const f32x4 (&yacc)[NT][KP / 16]) {
@@ -86,11 +87,7 @@ __device__ __forceinline__ void store_y(float* __restrict__ ybuf, long long row,
   for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
     for (int kt = 0; kt < KP / 16; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 16 * ct + 4 * g + r;
-        ybuf[(row * nchan + c) * KP + kt * 16 + j] = yacc[ct][kt][r];
-      }
+      *reinterpret_cast<f32x4*>(ybuf + (row * KP + kt * 16 + j) * nchan + 16 * ct + 4 * g) = yacc[ct][kt];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -167,32 +164,88 @@ __global__ __launch_bounds__(256) void pw_mlp2_kernel(const MlpParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc2[ot][q] = bias2[ot];
 
-      for (int t = 0; t < ntile; ++t) {
-        f32x4 acc1[4];
+      // Software pipeline over the 16-channel hidden tiles: while the VALU runs GELU on tile t the
+      // matrix pipe runs layer 2 of tile t-1 and layer 1 of tile t+1 (independent chains), so the
+      // two pipes overlap inside ONE wave instead of relying on a partner wave being out of phase.
+      auto fc1 = [&](int t, f32x4(&a1)[4]) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc1[q] = bb;
+        for (int q = 0; q < 4; ++q) a1[q] = bb;
 #pragma unroll
         for (int s = 0; s < CIN_STEPS; ++s) {
           const float a = s_w1[(t * CIN_STEPS + s) * 64 + lane];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc1[q] = mfma16x16x4(a, xs[s][q], acc1[q]);
+          for (int q = 0; q < 4; ++q) a1[q] = mfma16x16x4(a, xs[s][q], a1[q]);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc1[q][r] = gelu_erf(acc1[q][r]);
-        // layer 2 sums over the hidden channel = ROW index of acc1 (row = 4g + r): register r of
-        // lane-group g is k-slot g of step r -- no lane movement, no LDS.
+      };
+      // layer 2 sums over the hidden channel = ROW index of the layer-1 accumulator (row = 4g + r):
+      // register r of lane-group g is k-slot g of step r -- no lane movement, no LDS.
+      auto fc2 = [&](int t, const f32x4(&gl)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int ot = 0; ot < COUT_TILES; ++ot) {
             const float a2 = s_w2[((t * 4 + r) * COUT_TILES + ot) * 64 + lane];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc2[ot][q] = mfma16x16x4(a2, acc1[q][r], acc2[ot][q]);
+            for (int q = 0; q < 4; ++q) acc2[ot][q] = mfma16x16x4(a2, gl[q][r], acc2[ot][q]);
           }
+      };
+      auto act = [&](const f32x4(&a1)[4], f32x4(&gl)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gl[q] = a1[q];
+        gelu_erf8(gl[0], gl[1]);
+        gelu_erf8(gl[2], gl[3]);
+      };
+      f32x4 a_cur[4], a_nxt[4], g_prev[4], g_new[4];
+      fc1(0, a_cur);
+      fc1(ntile > 1 ? 1 : 0, a_nxt);
+      act(a_cur, g_prev);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+      for (int t = 1; t < ntile; ++t) {
+        // Hand-interleaved trip: 16 slots, slot i = GELU of element i of tile t (VALU) + its share
+        // of the matrix work, i.e. layer 1 of tile t+1 and layer 2 of tile t-1 (both independent of
+        // the GELU in flight).  sched_barrier keeps hipcc from re-bunching the MFMAs: an in-order
+        // wave that issues them back to back stalls on the matrix pipe before any VALU can issue.
+        const int tn = (t + 1 < ntile) ? t + 1 : t;  // last trip: recompute tile t, result unused
+        constexpr int kN1 = 4 * CIN_STEPS, kNM = kN1 + 16 * COUT_TILES;
+        float w1r[CIN_STEPS], w2r[4][COUT_TILES];
+#pragma unroll
+        for (int s = 0; s < CIN_STEPS; ++s) w1r[s] = s_w1[(tn * CIN_STEPS + s) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ot = 0; ot < COUT_TILES; ++ot) w2r[r][ot] = s_w2[(((t - 1) * 4 + r) * COUT_TILES + ot) * 64 + lane];
+        {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * tn + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a_nxt[q] = bb;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int m = (i * kNM) / 2; m < ((i + 1) * kNM) / 2; ++m) {
+            if (m < kN1) {
+              const int sidx = m / 4, q = m % 4;
+              a_nxt[q] = mfma16x16x4(w1r[sidx], xs[sidx][q], a_nxt[q]);
+            } else {
+              const int mm = m - kN1;
+              const int r = mm / (4 * COUT_TILES), ot = (mm / 4) % COUT_TILES, q = mm % 4;
+              acc2[ot][q] = mfma16x16x4(w2r[r][ot], g_prev[q][r], acc2[ot][q]);
+            }
+          }
+          g_new[2 * i] = a_cur[2 * i];
+          g_new[2 * i + 1] = a_cur[2 * i + 1];
+          gelu_erf8(g_new[2 * i], g_new[2 * i + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          g_prev[q] = g_new[q];
+          a_cur[q] = a_nxt[q];
+        }
       }
+      fc2(ntile - 1, g_prev);
 
       // epilogue: acc2[ot][q][r] = out[co = 16 ot + 4 g + r][pixel 4 j + q]
 #pragma unroll
@@ -215,6 +268,135 @@ __global__ __launch_bounds__(256) void pw_mlp2_kernel(const MlpParams p) {
       }
     }
     if (EMIT_Y) store_y<COUT_TILES, KP>(p.ybuf, row, COUT_TILES * 16, lane, yacc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// projection with few outputs (CO <= 4):  out = W2 * gelu(W1 * h + b1) + b2 (+ residual)
+// Layer 1 (32 -> hid) stays on fp32 MFMA; layer 2 (hid -> CO) would waste 12+ of 16 MFMA rows, and
+// fp32 MFMA shares the fp32 lanes with the VALU on gfx950 (tools/ubench_fp32.hip: the two do not
+// overlap), so it is done with CO*16 plain FMAs per hidden tile and one 4-lane-group reduction at
+// the end.  Same software pipeline as pw_mlp2_kernel.
+//   p.w2p here is W2 re-tiled as [hid/16][CO][16].
+// ---------------------------------------------------------------------------------------------
+template <int CO, bool RESID>
+__global__ __launch_bounds__(256) void pw_proj_small_kernel(const MlpParams p) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int CS = 8;  // 32 input channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int ntile = p.hid >> 4;
+  float* s_w1 = smem;
+  float* s_b1 = s_w1 + ntile * CS * 64;
+  float* s_w2 = s_b1 + p.hid;  // [ntile][CO][16]
+  {
+    const int n1 = ntile * CS * 64, n2 = ntile * CO * 16;
+    for (int i = tid * 4; i < n1; i += blockDim.x * 4)
+      *reinterpret_cast<f32x4*>(s_w1 + i) = *reinterpret_cast<const f32x4*>(p.w1p + i);
+    for (int i = tid; i < p.hid; i += blockDim.x) s_b1[i] = p.b1[i];
+    for (int i = tid; i < n2; i += blockDim.x) s_w2[i] = p.w2p[i];
+  }
+  __syncthreads();
+  const int HW = p.H * p.W, segs = p.W >> 6, nrow = p.B * p.H;
+  for (int row = blockIdx.x * nw + wave; row < nrow; row += gridDim.x * nw) {
+    const int h = row % p.H, b = row / p.H;
+    for (int ws = 0; ws < segs; ++ws) {
+      const int w0 = ws * 64;
+      const long long pix = (long long)h * p.W + w0 + 4 * j;
+      f32x4 xs[CS];
+#pragma unroll
+      for (int s = 0; s < CS; ++s)
+        xs[s] = *reinterpret_cast<const f32x4*>(p.x.seg[0].ptr + (long long)b * p.x.seg[0].bstride +
+                                                (long long)(4 * s + g) * HW + pix);
+      float po[CO][4];
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) po[co][q] = 0.f;
+      auto fc1 = [&](int t, f32x4(&a1)[4]) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a1[q] = bb;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+          const float a = s_w1[(t * CS + s) * 64 + lane];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a1[q] = mfma16x16x4(a, xs[s][q], a1[q]);
+        }
+      };
+      f32x4 a_cur[4], a_nxt[4], g_prev[4], g_new[4];
+      fc1(0, a_cur);
+      fc1(ntile > 1 ? 1 : 0, a_nxt);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g_prev[q] = a_cur[q];
+      gelu_erf8(g_prev[0], g_prev[1]);
+      gelu_erf8(g_prev[2], g_prev[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+      for (int t = 1; t < ntile; ++t) {
+        const int tn = (t + 1 < ntile) ? t + 1 : t;
+        float w1r[CS];
+#pragma unroll
+        for (int s = 0; s < CS; ++s) w1r[s] = s_w1[(tn * CS + s) * 64 + lane];
+        f32x4 w2v[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+          w2v[co] = *reinterpret_cast<const f32x4*>(s_w2 + ((t - 1) * CO + co) * 16 + 4 * g);
+        {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * tn + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a_nxt[q] = bb;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int m = 16 * i; m < 16 * i + 16; ++m) a_nxt[m % 4] = mfma16x16x4(w1r[m / 4], xs[m / 4][m % 4], a_nxt[m % 4]);
+          g_new[2 * i] = a_cur[2 * i];
+          g_new[2 * i + 1] = a_cur[2 * i + 1];
+          gelu_erf8(g_new[2 * i], g_new[2 * i + 1]);
+#pragma unroll
+          for (int co = 0; co < CO; ++co)
+#pragma unroll
+            for (int qq = 2 * i; qq < 2 * i + 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) po[co][qq] = fmaf(w2v[co][r], g_prev[qq][r], po[co][qq]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          g_prev[q] = g_new[q];
+          a_cur[q] = a_nxt[q];
+        }
+      }
+      {
+        const int t = ntile - 1;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_w2 + (t * CO + co) * 16 + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) po[co][q] = fmaf(w2[r], g_prev[q][r], po[co][q]);
+        }
+      }
+      // sum the 4 lane groups (hidden channels 4g+r of every tile live in group g)
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = po[co][q];
+          x += __shfl_xor(x, 16);
+          x += __shfl_xor(x, 32);
+          if (g == co) v[q] = x;
+        }
+      if (g < CO && g < p.cout) {
+        const float bias = p.b2[g];
+        v += f32x4{bias, bias, bias, bias};
+        if (RESID) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)b * p.resid_bstride + (long long)g * HW + pix);
+        *reinterpret_cast<f32x4*>(p.out + (long long)b * p.out_bstride + (long long)g * HW + pix) = v;
+      }
+    }
   }
 }
 
@@ -309,18 +491,25 @@ __global__ __launch_bounds__(256) void fno_layer_kernel(const LayerParams p) {
           acc[1][q] = mfma16x16x4(z[s][1], tw[q], acc[1][q]);
         }
       }
+      f32x4 vv[2][4];
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[ot][r] = f32x4{acc[ot][0][r], acc[ot][1][r], acc[ot][2][r], acc[ot][3][r]};
+      if (ACT) {
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+          gelu_erf8(vv[ot][0], vv[ot][1]);
+          gelu_erf8(vv[ot][2], vv[ot][3]);
+        }
+      }
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = 16 * ot + 4 * g + r;
-          f32x4 v = {acc[ot][0][r], acc[ot][1][r], acc[ot][2][r], acc[ot][3][r]};
-          if (ACT) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
-          }
-          *reinterpret_cast<f32x4*>(p.y + ((long long)b * kC + co) * HW + pix) = v;
-          if (EMIT_Y) *reinterpret_cast<f32x4*>(s_tr + co * kTrStride + 4 * j) = v;
+          *reinterpret_cast<f32x4*>(p.y + ((long long)b * kC + co) * HW + pix) = vv[ot][r];
+          if (EMIT_Y) *reinterpret_cast<f32x4*>(s_tr + co * kTrStride + 4 * j) = vv[ot][r];
         }
       if (EMIT_Y) {
         wave_lds_fence();
@@ -366,78 +555,140 @@ __global__ __launch_bounds__(256) void fwd_dft_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// modes kernel: per (sample b, rfft column ky)
-//   X[r][c] = fwd_scale * sum_h EF[r][h] * Y[h][c]           (H-direction pruned DFT, M1 rows)
-//   O[r][o] = sum_c X[r][c] * Wt[ky][r][c][o]                (einsum 'bixy,ioxy->boxy')
-//   Z[h][o] = ck[ky] * sum_r EI[r][h] * O[r][o]              (inverse H-direction)
-// blocks with ky >= M2 zero the padding rows of Z.
+// modes kernel: one workgroup (256 threads) per (sample b, rfft column ky)
+//   P1  X[r][c] = fwd_scale * sum_h EF[r][h] * Y[h][c]        (H-direction pruned DFT, M1 rows)
+//   P2  O[r][o] = sum_c X[r][c] * Wt[ky][r][c][o]             (einsum 'bixy,ioxy->boxy')
+//   P3  Z[h][o] = ck[ky] * sum_r EI[r][h] * O[r][o]           (inverse H-direction)
+// Thread (lo = tid & 31, hi = tid >> 5): lo is the channel, hi splits h (P1, P3) or r (P2) 8 ways.
+// The (ky) weight slice [M1][C][C] complex is pulled into LDS by LDS-DMA at kernel entry and is
+// only waited for before P2, so its L2 latency hides behind P1.  Blocks with ky >= M2 zero the
+// padding rows of Z.
 // ---------------------------------------------------------------------------------------------
 struct ModesParams {
-  const float* ybuf;   // [B][H][C][KP]
+  const float* ybuf;   // [B][H][KP][C]
   float* zbuf;         // [B][H][KP][C]
   const float2* wt;    // [M2][M1][C][C]
   const float2* ef;    // [M1][H]  (cos, -sin) of 2 pi kx_in h / H
   const float2* ei;    // [M1][H]  (cos, +sin) of 2 pi kx_out h / H
   const float* ck;     // [M2]  Hermitian weight (1 or 2) * inv_scale
   float fwd_scale;
-  int B, H, C, M1, M2, KP;
+  int B, H, M1, M2, KP;
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return float2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
-}
 __device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 c) {
   return float2{fmaf(a.x, b.x, fmaf(-a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, c.y))};
 }
 
+// HC = ceil(H / 8): h values per thread;  MR = ceil(M1 / 8): weight rows per thread.
+// The (ky) weight slice [M1][C][C] complex goes straight to registers (MR*32 float2 per thread),
+// requested right after the Y loads and first used in P2, so its L2 latency hides behind P1.
+template <int HC, int MR>
 __global__ __launch_bounds__(256) void fno_modes_kernel(const ModesParams p) {
   extern __shared__ __align__(16) float smem[];
-  const int ky = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-  const int H = p.H, C = p.C, M1 = p.M1, KP = p.KP;
+  constexpr int C = kC;
+  const int ky = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int lo = tid & 31, hi = tid >> 5;
+  const int H = p.H, M1 = p.M1, KP = p.KP;
   float* zb = p.zbuf + (long long)b * H * KP * C;
-  if (ky >= p.M2) {  // zero padding rows k' = 2ky, 2ky+1
-    for (int i = tid; i < H * C; i += nt) {
-      const int o = i % C, h = i / C;
+  if (ky >= p.M2) {
+    for (int i = tid; i < H * C; i += 256) {
+      const int o = i & 31, h = i >> 5;
       zb[((long long)h * KP + 2 * ky) * C + o] = 0.f;
       zb[((long long)h * KP + 2 * ky + 1) * C + o] = 0.f;
     }
     return;
   }
-  float2* s_y = reinterpret_cast<float2*>(smem);  // [H][C]
-  float2* s_x = s_y + H * C;                      // [M1][C]
-  float2* s_o = s_x + M1 * C;                     // [M1][C]
-  float2* s_ef = s_o + M1 * C;                    // [M1][H]
-  float2* s_ei = s_ef + M1 * H;                   // [M1][H]
-  const float* yb = p.ybuf + (long long)b * H * C * KP;
-  for (int i = tid; i < H * C; i += nt)
-    s_y[i] = *reinterpret_cast<const float2*>(yb + (long long)i * KP + 2 * ky);
-  for (int i = tid; i < M1 * H; i += nt) {
+  float2* s_ef = reinterpret_cast<float2*>(smem);   // [M1][H]
+  float2* s_ei = s_ef + M1 * H;                     // [M1][H]
+  float2* s_part = s_ei + M1 * H;                   // [4 waves][M1][C]  P1 partial sums
+  float2* s_x = s_part + 4 * M1 * C;                // [M1][C]
+  float2* s_o = s_x + M1 * C;                       // [M1][C]
+
+  // (1) Y slice of this thread: column c = lo, rows hi*HC .. hi*HC+HC-1
+  float2 yv[HC];
+  {
+    const float* yb = p.ybuf + (long long)b * H * KP * C;
+#pragma unroll
+    for (int i = 0; i < HC; ++i) {
+      const int h = hi * HC + i;
+      if (h < H) {
+        yv[i].x = yb[((long long)h * KP + 2 * ky) * C + lo];
+        yv[i].y = yb[((long long)h * KP + 2 * ky + 1) * C + lo];
+      } else {
+        yv[i] = float2{0.f, 0.f};
+      }
+    }
+  }
+  // (2) twiddle tables -> LDS
+  for (int i = tid; i < M1 * H; i += 256) {
     s_ef[i] = p.ef[i];
     s_ei[i] = p.ei[i];
   }
-  __syncthreads();
-  for (int i = tid; i < M1 * C; i += nt) {
-    const int c = i % C, r = i / C;
+  // (3) weights of the rows this thread owns in P2: r = hi + 8 m, output o = lo
+  float2 wreg[MR][C];
+  {
+    const float2* wsl = p.wt + (long long)ky * M1 * C * C;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const int r = hi + 8 * m;
+      const float2* w = wsl + (size_t)(r < M1 ? r : 0) * C * C + lo;
+#pragma unroll
+      for (int c = 0; c < C; ++c) wreg[m][c] = w[c * C];
+    }
+  }
+  __syncthreads();  // tables visible (plain loads stay in flight across the barrier)
+  // P1
+  for (int r = 0; r < M1; ++r) {
     float2 acc = {0.f, 0.f};
-    for (int h = 0; h < H; ++h) acc = cfma(s_y[h * C + c], s_ef[r * H + h], acc);
-    s_x[i] = float2{acc.x * p.fwd_scale, acc.y * p.fwd_scale};
+#pragma unroll
+    for (int i = 0; i < HC; ++i) {
+      const int h = hi * HC + i;
+      acc = cfma(yv[i], s_ef[r * H + (h < H ? h : 0)], acc);
+    }
+    acc.x += __shfl_xor(acc.x, 32);  // the two half-waves (hi even / odd)
+    acc.y += __shfl_xor(acc.y, 32);
+    if ((tid & 32) == 0) s_part[((tid >> 6) * M1 + r) * C + lo] = acc;
   }
   __syncthreads();
-  for (int i = tid; i < M1 * C; i += nt) {
-    const int o = i % C, r = i / C;
-    const float2* w = p.wt + ((long long)(ky * M1 + r) * C) * C + o;
-    float2 acc = {0.f, 0.f};
-    for (int c = 0; c < C; ++c) acc = cfma(s_x[r * C + c], w[(long long)c * C], acc);
-    s_o[i] = acc;
+  for (int i = tid; i < M1 * C; i += 256) {
+    const float2 a0 = s_part[i], a1 = s_part[M1 * C + i], a2 = s_part[2 * M1 * C + i], a3 = s_part[3 * M1 * C + i];
+    s_x[i] = float2{((a0.x + a1.x) + (a2.x + a3.x)) * p.fwd_scale, ((a0.y + a1.y) + (a2.y + a3.y)) * p.fwd_scale};
   }
   __syncthreads();
-  const float ck = p.ck[ky];
-  for (int i = tid; i < H * C; i += nt) {
-    const int o = i % C, h = i / C;
-    float2 acc = {0.f, 0.f};
-    for (int r = 0; r < M1; ++r) acc = cfma(s_o[r * C + o], s_ei[r * H + h], acc);
-    zb[((long long)h * KP + 2 * ky) * C + o] = acc.x * ck;
-    zb[((long long)h * KP + 2 * ky + 1) * C + o] = acc.y * ck;
+  // P2
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const int r = hi + 8 * m;
+    if (r < M1) {
+      float2 acc = {0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc = cfma(s_x[r * C + c], wreg[m][c], acc);
+      s_o[r * C + lo] = acc;
+    }
+  }
+  __syncthreads();
+  // P3
+  {
+    float2 acc[HC];
+#pragma unroll
+    for (int i = 0; i < HC; ++i) acc[i] = float2{0.f, 0.f};
+    for (int r = 0; r < M1; ++r) {
+      const float2 ov = s_o[r * C + lo];
+#pragma unroll
+      for (int i = 0; i < HC; ++i) {
+        const int h = hi * HC + i;
+        acc[i] = cfma(ov, s_ei[r * H + (h < H ? h : 0)], acc[i]);
+      }
+    }
+    const float ck = p.ck[ky];
+#pragma unroll
+    for (int i = 0; i < HC; ++i) {
+      const int h = hi * HC + i;
+      if (h < H) {
+        zb[((long long)h * KP + 2 * ky) * C + lo] = acc[i].x * ck;
+        zb[((long long)h * KP + 2 * ky + 1) * C + lo] = acc[i].y * ck;
+      }
+    }
   }
 }
 
@@ -489,7 +740,7 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
     DLWP_HIP_CHECK(hipStreamSynchronize(s));  // host staging vectors die at scope exit
     return DLWP_OK;
   }
-  size_t modes_lds_bytes() const { return (size_t)(H * kC + 2 * M1 * kC + 2 * M1 * H) * sizeof(float2); }
+  size_t modes_lds_bytes() const { return (size_t)(2 * M1 * H + 6 * M1 * kC) * sizeof(float2); }
 };
 
 // pack spectral weights [Ci][Co][M1][M2][2] (optionally two row blocks) -> Wt[M2][M1tot][Ci][Co] complex
@@ -519,18 +770,49 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
                              (int)bytes);
 }
 
+template <int HC>
+static int32_t launch_modes_hc(const ModesParams& mp, size_t lds, dim3 grid, hipStream_t s) {
+  const int mr = (mp.M1 + 7) / 8;
+  switch (mr) {
+    case 1:
+      DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 1>, lds));
+      hipLaunchKernelGGL((fno_modes_kernel<HC, 1>), grid, dim3(256), lds, s, mp);
+      break;
+    case 2:
+      DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 2>, lds));
+      hipLaunchKernelGGL((fno_modes_kernel<HC, 2>), grid, dim3(256), lds, s, mp);
+      break;
+    case 3:
+      DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 3>, lds));
+      hipLaunchKernelGGL((fno_modes_kernel<HC, 3>), grid, dim3(256), lds, s, mp);
+      break;
+    case 4:
+      DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 4>, lds));
+      hipLaunchKernelGGL((fno_modes_kernel<HC, 4>), grid, dim3(256), lds, s, mp);
+      break;
+    default:
+      return fail(DLWP_ERR_UNSUPPORTED, "more than 32 kept spectral rows (%d) not supported", mp.M1);
+  }
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
 static int32_t launch_modes(const SpectralCore& sc, const float* ybuf, float* zbuf, const float2* wt, int B,
                             hipStream_t s) {
   ModesParams mp;
   mp.ybuf = ybuf; mp.zbuf = zbuf; mp.wt = wt;
   mp.ef = sc.ef.as<float2>(); mp.ei = sc.ei.as<float2>(); mp.ck = sc.ck.as<float>();
   mp.fwd_scale = sc.fwd_scale;
-  mp.B = B; mp.H = sc.H; mp.C = kC; mp.M1 = sc.M1; mp.M2 = sc.M2; mp.KP = sc.KP;
+  mp.B = B; mp.H = sc.H; mp.M1 = sc.M1; mp.M2 = sc.M2; mp.KP = sc.KP;
   const size_t lds = sc.modes_lds_bytes();
-  DLWP_HIP_CHECK(allow_lds(fno_modes_kernel, lds));
-  hipLaunchKernelGGL(fno_modes_kernel, dim3(sc.KP / 2, B), dim3(256), lds, s, mp);
-  DLWP_HIP_CHECK(hipGetLastError());
-  return DLWP_OK;
+  DLWP_REQUIRE(lds <= 160 * 1024, DLWP_ERR_UNSUPPORTED, "modes kernel needs %zu bytes of LDS", lds);
+  const dim3 grid(sc.KP / 2, B);
+  const int hc = (sc.H + 7) / 8;
+  if (hc <= 4) return launch_modes_hc<4>(mp, lds, grid, s);
+  if (hc <= 8) return launch_modes_hc<8>(mp, lds, grid, s);
+  if (hc <= 16) return launch_modes_hc<16>(mp, lds, grid, s);
+  if (hc <= 32) return launch_modes_hc<32>(mp, lds, grid, s);
+  return fail(DLWP_ERR_UNSUPPORTED, "grid height %d > 256 not supported by the modes kernel", sc.H);
 }
 
 template <bool SKIP, bool ACT, bool EMIT_Y>
@@ -560,7 +842,8 @@ struct dlwp_fno2d_plan {
   int cin_steps = 0;
   SpectralCore sc;
   DevBuf lift_w1p, lift_b1, lift_w2p, lift_b2;
-  DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2;
+  DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v;
+  int proj_co = 0;  // outputs handled by pw_proj_small_kernel (1, 2 or 4), 0 = generic MFMA path
   std::vector<DevBuf> wt, wsp, sbias;
 };
 
@@ -629,6 +912,15 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
     pack_w2(tmp, d->proj_w2, p->hid_p, p->cout, 1);
     if ((e = up(p->proj_w2p, tmp)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+    if (p->cout <= 4) {
+      p->proj_co = p->cout <= 1 ? 1 : (p->cout <= 2 ? 2 : 4);
+      std::vector<float> wv((size_t)(p->hid_p / 16) * p->proj_co * 16, 0.f);
+      for (int t = 0; t < p->hid_p / 16; ++t)
+        for (int co = 0; co < p->cout; ++co)
+          for (int k = 0; k < 16; ++k) wv[((size_t)t * p->proj_co + co) * 16 + k] = d->proj_w2[(size_t)co * p->hid_p + 16 * t + k];
+      if ((e = up(p->proj_w2v, wv)) != hipSuccess) break;
+      if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+    }
     std::vector<float> b2(16, 0.f);
     for (int i = 0; i < p->cout; ++i) b2[i] = d->proj_b2[i];
     if ((e = up(p->proj_b2, b2)) != hipSuccess) break;
@@ -777,7 +1069,19 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     const size_t lds = ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * 4 * 1 * 64) * 4;
     const int grid = grid_rows(nrow, 4);
     if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::PROJ));
-    if (resid) {
+    if (p->proj_co > 0) {
+      mp.w2p = p->proj_w2v.as<float>();
+      const size_t lds2 = ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4;
+#define DLWP_LAUNCH_PROJ(CO_, RES_)                                                                     \
+  do {                                                                                                  \
+    DLWP_HIP_CHECK(allow_lds(pw_proj_small_kernel<CO_, RES_>, lds2));                                   \
+    hipLaunchKernelGGL((pw_proj_small_kernel<CO_, RES_>), dim3(grid), dim3(256), lds2, s, mp);          \
+  } while (0)
+      if (p->proj_co == 1) { if (resid) DLWP_LAUNCH_PROJ(1, true); else DLWP_LAUNCH_PROJ(1, false); }
+      else if (p->proj_co == 2) { if (resid) DLWP_LAUNCH_PROJ(2, true); else DLWP_LAUNCH_PROJ(2, false); }
+      else { if (resid) DLWP_LAUNCH_PROJ(4, true); else DLWP_LAUNCH_PROJ(4, false); }
+#undef DLWP_LAUNCH_PROJ
+    } else if (resid) {
       DLWP_HIP_CHECK(allow_lds(pw_mlp2_kernel<8, 1, 16, false, true>, lds));
       hipLaunchKernelGGL((pw_mlp2_kernel<8, 1, 16, false, true>), dim3(grid), dim3(256), lds, s, mp);
     } else {
