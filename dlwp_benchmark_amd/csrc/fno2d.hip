@@ -579,19 +579,22 @@ __device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 c) {
   return float2{fmaf(a.x, b.x, fmaf(-a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, c.y))};
 }
 
-// HC = ceil(H / 8): h values per thread;  MR = ceil(M1 / 8): weight rows per thread.
-// The (ky) weight slice [M1][C][C] complex goes straight to registers (MR*32 float2 per thread),
-// requested right after the Y loads and first used in P2, so its L2 latency hides behind P1.
-template <int HC, int MR>
-__global__ __launch_bounds__(256) void fno_modes_kernel(const ModesParams p) {
+// 1024 threads = 16 waves = 4 per SIMD: on gfx950 a lone wave issues one VALU op per ~6 cycles, four
+// waves per SIMD one per ~2.8 (tools/ubench_fp32.hip), and this kernel is pure VALU + latency.
+// Thread (lo = tid & 31, hi = tid >> 5 in 0..31): lo = channel; hi splits h 32 ways in P1 / P3 and
+// (r, half of the c-sum) in P2.  HC = ceil(H / 32).  RG = 16 or 32 row slots (M1 <= RG).
+// The weights a thread needs in P2 (32*16/RG float2) are requested right after the Y loads and first
+// used in P2, so their L2 latency hides behind P1.
+template <int HC, int RG>
+__global__ __launch_bounds__(1024) void fno_modes_kernel(const ModesParams p) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int C = kC;
+  constexpr int C = kC, CP = 32 / RG, CN = C / CP;  // CP c-parts, CN channels summed per thread in P2
   const int ky = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int lo = tid & 31, hi = tid >> 5;
   const int H = p.H, M1 = p.M1, KP = p.KP;
   float* zb = p.zbuf + (long long)b * H * KP * C;
   if (ky >= p.M2) {
-    for (int i = tid; i < H * C; i += 256) {
+    for (int i = tid; i < H * C; i += 1024) {
       const int o = i & 31, h = i >> 5;
       zb[((long long)h * KP + 2 * ky) * C + o] = 0.f;
       zb[((long long)h * KP + 2 * ky + 1) * C + o] = 0.f;
@@ -600,11 +603,10 @@ __global__ __launch_bounds__(256) void fno_modes_kernel(const ModesParams p) {
   }
   float2* s_ef = reinterpret_cast<float2*>(smem);   // [M1][H]
   float2* s_ei = s_ef + M1 * H;                     // [M1][H]
-  float2* s_part = s_ei + M1 * H;                   // [4 waves][M1][C]  P1 partial sums
-  float2* s_x = s_part + 4 * M1 * C;                // [M1][C]
+  float2* s_part = s_ei + M1 * H;                   // [16 waves][M1][C]  P1 partials, reused as [CP][M1][C] in P2
+  float2* s_x = s_part + 16 * M1 * C;               // [M1][C]
   float2* s_o = s_x + M1 * C;                       // [M1][C]
 
-  // (1) Y slice of this thread: column c = lo, rows hi*HC .. hi*HC+HC-1
   float2 yv[HC];
   {
     const float* yb = p.ybuf + (long long)b * H * KP * C;
@@ -619,25 +621,19 @@ __global__ __launch_bounds__(256) void fno_modes_kernel(const ModesParams p) {
       }
     }
   }
-  // (2) twiddle tables -> LDS
-  for (int i = tid; i < M1 * H; i += 256) {
+  for (int i = tid; i < M1 * H; i += 1024) {
     s_ef[i] = p.ef[i];
     s_ei[i] = p.ei[i];
   }
-  // (3) weights of the rows this thread owns in P2: r = hi + 8 m, output o = lo
-  float2 wreg[MR][C];
+  const int r2 = hi % RG, cpart = hi / RG;
+  float2 wreg[CN];
   {
-    const float2* wsl = p.wt + (long long)ky * M1 * C * C;
+    const float2* w = p.wt + ((long long)ky * M1 + (r2 < M1 ? r2 : 0)) * C * C + (size_t)cpart * CN * C + lo;
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-      const int r = hi + 8 * m;
-      const float2* w = wsl + (size_t)(r < M1 ? r : 0) * C * C + lo;
-#pragma unroll
-      for (int c = 0; c < C; ++c) wreg[m][c] = w[c * C];
-    }
+    for (int c = 0; c < CN; ++c) wreg[c] = w[c * C];
   }
-  __syncthreads();  // tables visible (plain loads stay in flight across the barrier)
-  // P1
+  __syncthreads();
+  // P1: X[r][c] partial over this thread's h slice
   for (int r = 0; r < M1; ++r) {
     float2 acc = {0.f, 0.f};
 #pragma unroll
@@ -645,26 +641,39 @@ __global__ __launch_bounds__(256) void fno_modes_kernel(const ModesParams p) {
       const int h = hi * HC + i;
       acc = cfma(yv[i], s_ef[r * H + (h < H ? h : 0)], acc);
     }
-    acc.x += __shfl_xor(acc.x, 32);  // the two half-waves (hi even / odd)
+    acc.x += __shfl_xor(acc.x, 32);
     acc.y += __shfl_xor(acc.y, 32);
     if ((tid & 32) == 0) s_part[((tid >> 6) * M1 + r) * C + lo] = acc;
   }
   __syncthreads();
-  for (int i = tid; i < M1 * C; i += 256) {
-    const float2 a0 = s_part[i], a1 = s_part[M1 * C + i], a2 = s_part[2 * M1 * C + i], a3 = s_part[3 * M1 * C + i];
-    s_x[i] = float2{((a0.x + a1.x) + (a2.x + a3.x)) * p.fwd_scale, ((a0.y + a1.y) + (a2.y + a3.y)) * p.fwd_scale};
+  for (int i = tid; i < M1 * C; i += 1024) {
+    float2 a = s_part[i];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+      const float2 t = s_part[w * M1 * C + i];
+      a.x += t.x;
+      a.y += t.y;
+    }
+    s_x[i] = float2{a.x * p.fwd_scale, a.y * p.fwd_scale};
   }
   __syncthreads();
-  // P2
+  // P2: O[r][o] partial over this thread's c slice
+  if (r2 < M1) {
+    float2 acc = {0.f, 0.f};
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
-    const int r = hi + 8 * m;
-    if (r < M1) {
-      float2 acc = {0.f, 0.f};
+    for (int c = 0; c < CN; ++c) acc = cfma(s_x[r2 * C + cpart * CN + c], wreg[c], acc);
+    s_part[(cpart * M1 + r2) * C + lo] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < M1 * C; i += 1024) {
+    float2 a = s_part[i];
 #pragma unroll
-      for (int c = 0; c < C; ++c) acc = cfma(s_x[r * C + c], wreg[m][c], acc);
-      s_o[r * C + lo] = acc;
+    for (int cp = 1; cp < CP; ++cp) {
+      const float2 t = s_part[cp * M1 * C + i];
+      a.x += t.x;
+      a.y += t.y;
     }
+    s_o[i] = a;
   }
   __syncthreads();
   // P3
@@ -740,7 +749,7 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
     DLWP_HIP_CHECK(hipStreamSynchronize(s));  // host staging vectors die at scope exit
     return DLWP_OK;
   }
-  size_t modes_lds_bytes() const { return (size_t)(2 * M1 * H + 6 * M1 * kC) * sizeof(float2); }
+  size_t modes_lds_bytes() const { return (size_t)(2 * M1 * H + 18 * M1 * kC) * sizeof(float2); }
 };
 
 // pack spectral weights [Ci][Co][M1][M2][2] (optionally two row blocks) -> Wt[M2][M1tot][Ci][Co] complex
@@ -772,26 +781,14 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
 
 template <int HC>
 static int32_t launch_modes_hc(const ModesParams& mp, size_t lds, dim3 grid, hipStream_t s) {
-  const int mr = (mp.M1 + 7) / 8;
-  switch (mr) {
-    case 1:
-      DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 1>, lds));
-      hipLaunchKernelGGL((fno_modes_kernel<HC, 1>), grid, dim3(256), lds, s, mp);
-      break;
-    case 2:
-      DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 2>, lds));
-      hipLaunchKernelGGL((fno_modes_kernel<HC, 2>), grid, dim3(256), lds, s, mp);
-      break;
-    case 3:
-      DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 3>, lds));
-      hipLaunchKernelGGL((fno_modes_kernel<HC, 3>), grid, dim3(256), lds, s, mp);
-      break;
-    case 4:
-      DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 4>, lds));
-      hipLaunchKernelGGL((fno_modes_kernel<HC, 4>), grid, dim3(256), lds, s, mp);
-      break;
-    default:
-      return fail(DLWP_ERR_UNSUPPORTED, "more than 32 kept spectral rows (%d) not supported", mp.M1);
+  if (mp.M1 <= 16) {
+    DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 16>, lds));
+    hipLaunchKernelGGL((fno_modes_kernel<HC, 16>), grid, dim3(1024), lds, s, mp);
+  } else if (mp.M1 <= 32) {
+    DLWP_HIP_CHECK(allow_lds(fno_modes_kernel<HC, 32>, lds));
+    hipLaunchKernelGGL((fno_modes_kernel<HC, 32>), grid, dim3(1024), lds, s, mp);
+  } else {
+    return fail(DLWP_ERR_UNSUPPORTED, "more than 32 kept spectral rows (%d) not supported", mp.M1);
   }
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
@@ -807,11 +804,11 @@ static int32_t launch_modes(const SpectralCore& sc, const float* ybuf, float* zb
   const size_t lds = sc.modes_lds_bytes();
   DLWP_REQUIRE(lds <= 160 * 1024, DLWP_ERR_UNSUPPORTED, "modes kernel needs %zu bytes of LDS", lds);
   const dim3 grid(sc.KP / 2, B);
-  const int hc = (sc.H + 7) / 8;
+  const int hc = (sc.H + 31) / 32;
+  if (hc <= 1) return launch_modes_hc<1>(mp, lds, grid, s);
+  if (hc <= 2) return launch_modes_hc<2>(mp, lds, grid, s);
   if (hc <= 4) return launch_modes_hc<4>(mp, lds, grid, s);
   if (hc <= 8) return launch_modes_hc<8>(mp, lds, grid, s);
-  if (hc <= 16) return launch_modes_hc<16>(mp, lds, grid, s);
-  if (hc <= 32) return launch_modes_hc<32>(mp, lds, grid, s);
   return fail(DLWP_ERR_UNSUPPORTED, "grid height %d > 256 not supported by the modes kernel", sc.H);
 }
 
