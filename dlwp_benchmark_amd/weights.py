@@ -61,40 +61,52 @@ def default_std(name: str, shape, gain: float = 1.0) -> float:
     return 0.02
 
 
-def fill_state_dict(model: torch.nn.Module, seed: int = 1234, std_fn=None, gain: float = 1.0) -> str:
-    """Fills every floating-point parameter in place; returns the SHA-256 of the blob.
+def value_for(name: str, shape, is_complex: bool = False, seed: int = 1234, std_fn=None, gain: float = 1.0):
+    """The filler's value for one named tensor (shared by fill_state_dict and fill_by_spec).
 
     Rules: *norm*.weight -> 1 + N(0, 0.05), *norm*.bias -> N(0, 0.05) (so affine terms are
     exercised); otherwise N(0, std) with std = std_fn(name, shape) if that returns a number,
-    else `default_std`.  Integer buffers (index tables) and float buffers (masks) are left as
-    constructed."""
+    else `default_std`."""
+    shape = tuple(int(d) for d in shape)
+    lname = name.lower()
+    std = std_fn(name, shape) if std_fn is not None else None
+    if is_complex:
+        if std is None:
+            std = default_std(name, shape, gain)
+        return torch.complex(normal(name + "/re", shape, std, seed), normal(name + "/im", shape, std, seed))
+    is_norm = ("norm" in lname) or (".ln" in lname)
+    if std is not None:
+        return normal(name, shape, std, seed)
+    if is_norm and name.endswith("weight"):
+        return 1.0 + normal(name, shape, 0.05, seed)
+    if is_norm and name.endswith("bias"):
+        return normal(name, shape, 0.05, seed)
+    return normal(name, shape, default_std(name, shape, gain), seed)
+
+
+def fill_state_dict(model: torch.nn.Module, seed: int = 1234, std_fn=None, gain: float = 1.0) -> str:
+    """Fills every floating-point / complex PARAMETER in place (see `value_for`); returns the SHA-256
+    of the blob.  Integer buffers (index tables) and float buffers (masks) are left as constructed."""
     sha = hashlib.sha256()
     with torch.no_grad():
         for name, p in model.named_parameters():
-            lname = name.lower()
-            shape = tuple(p.shape)
-            if p.is_complex():
-                std = std_fn(name, shape) if std_fn is not None else None
-                if std is None:
-                    std = default_std(name, shape, gain)
-                v = torch.complex(normal(name + "/re", shape, std, seed), normal(name + "/im", shape, std, seed))
-                p.copy_(v)
-                sha.update(name.encode())
-                sha.update(torch.view_as_real(v).numpy().tobytes())
+            if not (p.is_floating_point() or p.is_complex()):
                 continue
-            if not p.is_floating_point():
-                continue
-            is_norm = ("norm" in lname) or (".ln" in lname)
-            std = std_fn(name, shape) if std_fn is not None else None
-            if std is not None:
-                v = normal(name, shape, std, seed)
-            elif is_norm and name.endswith("weight"):
-                v = 1.0 + normal(name, shape, 0.05, seed)
-            elif is_norm and name.endswith("bias"):
-                v = normal(name, shape, 0.05, seed)
-            else:
-                v = normal(name, shape, default_std(name, shape, gain), seed)
+            v = value_for(name, tuple(p.shape), p.is_complex(), seed, std_fn, gain)
             p.copy_(v.to(p.dtype))
             sha.update(name.encode())
-            sha.update(v.numpy().tobytes())
+            sha.update((torch.view_as_real(v) if v.is_complex() else v).numpy().tobytes())
     return sha.hexdigest()
+
+
+def fill_by_spec(spec, seed: int = 1234, std_fn=None, gain: float = 1.0):
+    """spec: iterable of (name, shape) of float parameters -> (state dict, sha256), identical to what
+    `fill_state_dict` writes into a module whose named_parameters() match the spec."""
+    sha = hashlib.sha256()
+    out = {}
+    for name, shape in spec:
+        v = value_for(name, tuple(shape), False, seed, std_fn, gain)
+        out[name] = v
+        sha.update(name.encode())
+        sha.update(v.numpy().tobytes())
+    return out, sha.hexdigest()

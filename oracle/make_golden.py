@@ -64,12 +64,122 @@ def gen_spectral(ref):
         _save(f"spectral_conv2d_{tag}", y=y.numpy(), sha=np.array(tensor_sha(x, w1, w2)))
 
 
+# ------------------------------------------------------------------------------------------
+# whole backbones: reduced width on the real grid sizes (SURVEY.md section 8c "golden vectors")
+# ------------------------------------------------------------------------------------------
+MODEL_CASES = {
+    # tag: (family, cfg, (batch, frames), gain)
+    "swin_e32_32x64": ("swin", dict(constant_channels=4, prescribed_channels=1, prognostic_channels=3, context_size=1,
+                                    img_height=32, img_width=64, patch_size=1, embed_dim=32, depths=[2, 2],
+                                    num_heads=[2, 2], mlp_ratio=4, qkv_bias=True, drop_path_rate=0.2,
+                                    norm_layer="nn.LayerNorm", patch_norm=True), (2, 4), 1.0),
+    "swin_e16_p2_ctx2_32x64": ("swin", dict(constant_channels=4, prescribed_channels=1, prognostic_channels=2,
+                                            context_size=2, img_height=32, img_width=64, patch_size=2, embed_dim=16,
+                                            depths=[2, 2], num_heads=[2, 4], mlp_ratio=2, qkv_bias=True,
+                                            drop_path_rate=0.1, norm_layer="nn.LayerNorm", patch_norm=True), (2, 5), 1.0),
+    "afno_e16_32x64": ("afno", dict(img_height=32, img_width=64, patch_size=[1, 1], constant_channels=4,
+                                    prescribed_channels=1, prognostic_channels=3, filter="AFNO2D", embed_dim=16, depth=2,
+                                    mlp_ratio=4.0, num_blocks=4, sparsity_threshold=0.01,
+                                    hard_thresholding_fraction=1.0, context_size=1, use_pos_embed=True), (2, 4), 1.0),
+    "afno_e16_p2_64x64": ("afno", dict(img_height=64, img_width=64, patch_size=[2, 2], constant_channels=0,
+                                       prescribed_channels=0, prognostic_channels=1, filter="AFNO2D", embed_dim=16,
+                                       depth=2, mlp_ratio=2.0, num_blocks=2, sparsity_threshold=0.01,
+                                       hard_thresholding_fraction=0.5, context_size=1, use_pos_embed=True), (2, 3), 1.0),
+    "pangu_e48_32x64": ("pangu", dict(constant_channels=4, prescribed_channels=1, prognostic_channels=3, embed_dim=48,
+                                      num_heads=[2, 4, 4, 2], window_size=[2, 6, 12], patch_size=[1, 1], n_lat=32,
+                                      n_lon=64, context_size=1), (1, 3), 1.0),
+    "unet_h4_32x64": ("unet", dict(constant_channels=4, prescribed_channels=1, prognostic_channels=3,
+                                   hidden_channels=[4, 8, 16], n_convolutions=2, activation="th.nn.GELU()",
+                                   context_size=1), (2, 4), 1.0),
+    "unet_c1_64x64": ("unet", dict(constant_channels=0, prescribed_channels=0, prognostic_channels=1,
+                                   hidden_channels=[8, 16, 32, 64], n_convolutions=2, activation="th.nn.GELU()",
+                                   context_size=1), (2, 2), 1.0),
+    "convlstm_h8_32x64": ("convlstm", dict(batch_size=2, constant_channels=4, prescribed_channels=1,
+                                           prognostic_channels=3, hidden_sizes=[8, 8], height=32, width=64, bias=True,
+                                           context_size=2), (2, 6), 1.0),
+}
+
+
+def model_inputs(tag, cfg, batch, frames):
+    """Seeded inputs of the dataset tuple layout; identical on every machine (numpy Generator)."""
+    from dlwp_benchmark_amd.synthetic import navier_stokes, weatherbench
+
+    h = cfg.get("img_height", cfg.get("n_lat", cfg.get("height", 32)))
+    w = cfg.get("img_width", cfg.get("n_lon", cfg.get("width", 64)))
+    if "img_height" not in cfg and "n_lat" not in cfg and "height" not in cfg:
+        h, w = (64, 64) if cfg["constant_channels"] == 0 else (32, 64)
+    if cfg["constant_channels"] == 0 and cfg["prescribed_channels"] == 0:
+        return navier_stokes(batch, frames, h, w, channels=cfg["prognostic_channels"], seed=4321)
+    return weatherbench(batch, frames, h, w, prognostic_channels=cfg["prognostic_channels"],
+                        constant_channels=cfg["constant_channels"], prescribed_channels=cfg["prescribed_channels"],
+                        seed=4321)
+
+
+def build_reference(ref, family, cfg):
+    if family == "swin":
+        m = ref["swin"].SwinTransformer(**cfg)
+    elif family == "afno":
+        m = ref["fourcastnet"].AFNONet(**cfg)
+    elif family == "pangu":
+        m = ref["pangu"].PanguWeather(**cfg)
+    elif family == "unet":
+        m = ref["unet"].UNet(**cfg)
+        # documented runtime workaround for the reference defect (SURVEY.md 8c item 1)
+        for mod in m.encoder.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.padding = (0, 0)
+    elif family == "convlstm":
+        m = ref["convlstm"].ConvLSTM(**cfg)
+    else:
+        raise ValueError(family)
+    m.eval()   # as a statement: SwinTransformer.train() returns None (swin_transformer.py:739-742)
+    return m
+
+
+def reference_rollout(m, family, cfg, constants, prescribed, prognostic):
+    """Multi-step trajectory from the real reference.  AFNONet's in-model loop crashes on the 2nd
+    step as shipped (fourcastnet.py:336-340) -> single-step calls driven from here with the output
+    fed back (verified identical to the in-model loop on Swin, whose loop is the un-broken copy)."""
+    ctx = cfg["context_size"]
+    with torch.no_grad():
+        if family != "afno":
+            return m(constants=constants, prescribed=prescribed, prognostic=prognostic)
+        assert ctx == 1
+        outs, cur = [], prognostic[:, 0:1]
+        for t in range(1, prognostic.shape[1]):
+            step_in = torch.cat([cur, torch.zeros_like(cur)], dim=1)
+            pr = prescribed[:, t - 1:t + 1] if prescribed is not None else None
+            out = m(constants=constants, prescribed=pr, prognostic=step_in)
+            outs.append(out[:, 0])
+            cur = out[:, 0:1]
+        return torch.stack(outs, dim=1)
+
+
+def gen_models(ref, only=None):
+    import json
+
+    for tag, (family, cfg, (batch, frames), gain) in MODEL_CASES.items():
+        if only and tag not in only:
+            continue
+        m = build_reference(ref, family, cfg)
+        sha = W.fill_state_dict(m, gain=gain)
+        constants, prescribed, prognostic = model_inputs(tag, cfg, batch, frames)
+        y = reference_rollout(m, family, cfg, constants, prescribed, prognostic)
+        spec = [(k, list(v.shape)) for k, v in m.named_parameters()]
+        full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]
+        _save(f"model_{tag}", y=y.numpy().astype(np.float32), sha=np.array(sha),
+              param_spec=np.array(json.dumps(spec)), state_spec=np.array(json.dumps(full)))
+
+
 def main():
     if not ref_import.reference_available():
         raise SystemExit("reference tree not available: golden fixtures can only be regenerated in the build container")
     ref = ref_import.load_reference()
     torch.manual_seed(1234)
-    gen_spectral(ref)
+    only = set(sys.argv[1:])
+    if not only or "spectral" in only:
+        gen_spectral(ref)
+    gen_models(ref, only - {"spectral"} if only else None)
 
 
 if __name__ == "__main__":

@@ -26,3 +26,46 @@ def test_spectral_conv2d_restatement_matches_reference(tag):
     y = spectral_conv2d_ref(x, w1, w2)
     # same torch build on both sides -> bit-identical
     assert torch.equal(y, torch.from_numpy(g["y"]))
+
+
+# ------------------------------------------------------------------------------------------
+# whole backbones: functional restatements vs trajectories produced by the real reference
+# ------------------------------------------------------------------------------------------
+import json
+
+from dlwp_benchmark_amd.weights import fill_by_spec
+from oracle.make_golden import MODEL_CASES, model_inputs
+from oracle.restate import afno as R_afno
+from oracle.restate import pangu as R_pangu
+from oracle.restate import swin as R_swin
+from oracle.restate import unet as R_unet
+
+ROLLOUTS = {
+    "swin": R_swin.swin_rollout,
+    "afno": R_afno.afnonet_rollout,
+    "pangu": R_pangu.pangu_rollout,
+    "unet": R_unet.unet_rollout,
+    "convlstm": R_unet.convlstm_rollout,
+}
+
+
+def oracle_case(tag):
+    """(golden trajectory, oracle trajectory) for one MODEL_CASES entry."""
+    family, cfg, (batch, frames), gain = MODEL_CASES[tag]
+    g = load_golden(f"model_{tag}")
+    spec = json.loads(str(g["param_spec"]))
+    sd, sha = fill_by_spec(spec, gain=gain)
+    assert sha == str(g["sha"]), "filler drifted: regenerate fixtures"
+    constants, prescribed, prognostic = model_inputs(tag, cfg, batch, frames)
+    with torch.no_grad():
+        y = ROLLOUTS[family](sd, cfg, constants, prescribed, prognostic)
+    return torch.from_numpy(g["y"]), y
+
+
+@pytest.mark.parametrize("tag", list(MODEL_CASES))
+def test_backbone_restatement_matches_reference(tag):
+    want, got = oracle_case(tag)
+    assert got.shape == want.shape
+    # same torch build, same op sequence: expected bit-identical; allow last-ulp reassociation
+    err = rel_l2(got, want)
+    assert err < 1e-6, f"{tag}: rel L2 {err:.3e}"
