@@ -1,0 +1,366 @@
+// Fused (shifted-)window attention for the Swin and Pangu backbones on MI355X (gfx950).
+//
+// Replaces, per transformer block, everything between the qkv Linear and the proj Linear:
+//   Swin : swin_transformer.py:217-251 (pad, roll, window_partition, WindowAttention.forward :122-154
+//          minus its two Linears, window_reverse, roll back, crop) and the per-call mask build :383-401
+//   Pangu: panguweather.py:285-316 (ZeroPad3d, roll, window_partition, EarthAttention3D.forward
+//          :176-211 minus its two Linears, window_reverse, roll, crop3d), utils/shift_window_mask.py,
+//          utils/earth_position_index.py
+// Input is the qkv Linear output on the UN-padded, UN-shifted token sequence [B, L, 3, nH, d]; output
+// is [B, L, C] in the same token order.  Padding, cyclic shift (forward and backward shifts may
+// differ: Pangu's asymmetric roll, panguweather.py:291 vs :310), window partition / reverse, the
+// relative-position (Swin) or earth-specific (Pangu) bias gather and the 0/-100 shift mask are all
+// index arithmetic inside the kernel: none of those tensors is ever materialised.  Zero-padded
+// tokens take part in the softmax with q = k = v = qkv bias, exactly as in the reference (the pad is
+// applied before the Linear).
+//
+// Algorithm: flash-style streaming over 32-key tiles with online softmax, so the N x N score matrix
+// (N = 2048 for the reference Swin, whose window is the whole map) never exists.  Products run on
+// v_mfma_f32_16x16x4_f32 in the "swapped" orientation: S^T = K Q^T puts the key index on the
+// accumulator ROWS, which is the contraction index of the following O^T += V^T P^T -- the P tile is
+// consumed as an MFMA operand straight from the accumulator registers (no LDS round trip), and the
+// softmax statistics of a query live in one lane column.
+#include "common.hpp"
+
+namespace dlwp {
+namespace wattn {
+
+struct Desc {
+  int pl, lat, lon;           // un-padded token grid, L = pl*lat*lon
+  int ppl, plat, plon;        // padded grid
+  int pad_f, pad_t, pad_l;    // leading pads
+  int wpl, wlat, wlon;        // window
+  int npl, nlat, nlon;        // windows per dimension
+  int sf[3];                  // forward roll:  shifted[p] = padded[(p + sf) mod dim]
+  int sb[3];                  // backward roll: out_padded[(p + sb) mod dim] = attn_shifted[p]
+  int use_mask;               // 0/-100 shift mask on
+  int b1[3], b2[3];           // region id along a dim = (p >= b1) + (p >= b2), p in the shifted frame
+  int bias_mode;              // 0: Swin 2-D relative table [(2Wh-1)(2Ww-1)][nH]
+                              // 1: Pangu earth table [wpl^2 wlat^2 (2wlon-1)][types][nH]
+  int heads, d, C;            // C = heads*d
+  int N;                      // tokens per window
+  int table_rows, types;
+  float scale;
+};
+
+struct Coord {
+  int zpl, zlat, zlon;  // in-window coordinates
+  int region;           // shift-mask region id
+  long long src;        // token index in [0, L) or -1 for a zero-padded token
+};
+
+__device__ __forceinline__ Coord token_coord(const Desc& D, int ipl, int ilat, int ilon, int n) {
+  Coord c;
+  c.zlon = n % D.wlon;
+  const int t = n / D.wlon;
+  c.zlat = t % D.wlat;
+  c.zpl = t / D.wlat;
+  const int P = ipl * D.wpl + c.zpl, A = ilat * D.wlat + c.zlat, O = ilon * D.wlon + c.zlon;
+  const int rp = (P >= D.b1[0]) + (P >= D.b2[0]);
+  const int ra = (A >= D.b1[1]) + (A >= D.b2[1]);
+  const int ro = (O >= D.b1[2]) + (O >= D.b2[2]);
+  c.region = (rp * 3 + ra) * 3 + ro;
+  const int sp = (P + D.sf[0]) % D.ppl - D.pad_f;
+  const int sa = (A + D.sf[1]) % D.plat - D.pad_t;
+  const int so = (O + D.sf[2]) % D.plon - D.pad_l;
+  const bool ok = sp >= 0 && sp < D.pl && sa >= 0 && sa < D.lat && so >= 0 && so < D.lon;
+  c.src = ok ? ((long long)sp * D.lat + sa) * D.lon + so : -1;
+  return c;
+}
+
+__device__ __forceinline__ long long token_dest(const Desc& D, int ipl, int ilat, int ilon, int n) {
+  const int zlon = n % D.wlon;
+  const int t = n / D.wlon;
+  const int zlat = t % D.wlat, zpl = t / D.wlat;
+  const int dp = (ipl * D.wpl + zpl + D.sb[0]) % D.ppl - D.pad_f;
+  const int da = (ilat * D.wlat + zlat + D.sb[1]) % D.plat - D.pad_t;
+  const int dq = (ilon * D.wlon + zlon + D.sb[2]) % D.plon - D.pad_l;
+  const bool ok = dp >= 0 && dp < D.pl && da >= 0 && da < D.lat && dq >= 0 && dq < D.lon;
+  return ok ? ((long long)dp * D.lat + da) * D.lon + dq : -1;
+}
+
+__device__ __forceinline__ int pack_info(const Coord& c) {
+  return (c.zpl & 0xF) | ((c.zlat & 0xFF) << 4) | ((c.zlon & 0xFF) << 12) | ((c.region & 0x1F) << 20);
+}
+
+// DT = head_dim / 4 (k-steps of the QK^T product), DB = ceil(head_dim / 16) (16-row blocks of O^T)
+// SUB = 16-query sub-tiles per wave.  Block = 4 waves = 64*SUB queries of one (batch, window, head).
+template <int DT, int DB, int SUB>
+__global__ __launch_bounds__(256) void window_attn_f32_kernel(const Desc D, const float* __restrict__ qkv,
+                                                              const float* __restrict__ qkv_bias,
+                                                              const float* __restrict__ table,
+                                                              float* __restrict__ out, long long L) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int KT = 32;                 // keys per tile
+  constexpr int LDK = 4 * DT + 2;        // K tile row stride (floats): conflict-free A-operand reads
+  constexpr int LDV = 16 * DB + 4;       // V tile row stride
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y;
+  int wi = blockIdx.z;
+  const int nwin = D.npl * D.nlat * D.nlon;
+  const int b = wi / nwin;
+  wi -= b * nwin;
+  const int ilat = wi % D.nlat;
+  const int t2 = wi / D.nlat;
+  const int ipl = t2 % D.npl, ilon = t2 / D.npl;
+  const int d = D.d, C = D.C, N = D.N;
+
+  float* s_tab = smem;                          // [table_rows] bias column of this (type, head)
+  float* s_k = s_tab + ((D.table_rows + 3) & ~3);  // [KT][LDK]
+  float* s_v = s_k + KT * LDK;                  // [KT][LDV]
+  int* s_info = reinterpret_cast<int*>(s_v + KT * LDV);  // [KT] packed key coords (+ -1 beyond N)
+
+  {  // bias column -> LDS
+    const int type = ipl * D.nlat + ilat;
+    const long long stride = D.bias_mode ? (long long)D.types * D.heads : D.heads;
+    const float* col = table + (D.bias_mode ? (long long)type * D.heads : 0) + head;
+    for (int i = tid; i < D.table_rows; i += 256) s_tab[i] = col[i * stride];
+  }
+
+  const float* qkv_b = qkv + (long long)b * L * 3 * C;
+  const int q_base = blockIdx.x * (64 * SUB) + wave * (16 * SUB);
+  // Q^T operands (B operand: B[k = g][col = query j]) pre-scaled; query coordinates per lane column
+  float qreg[SUB][DT];
+  int qinfo[SUB];
+#pragma unroll
+  for (int sub = 0; sub < SUB; ++sub) {
+    const int qn = q_base + 16 * sub + j;
+    if (qn < N) {
+      const Coord c = token_coord(D, ipl, ilat, ilon, qn);
+      qinfo[sub] = pack_info(c);
+#pragma unroll
+      for (int s = 0; s < DT; ++s) {
+        const int e = 4 * s + g;
+        const float v = (c.src >= 0) ? qkv_b[c.src * 3 * C + head * d + e] : qkv_bias[head * d + e];
+        qreg[sub][s] = v * D.scale;
+      }
+    } else {
+      qinfo[sub] = 0;
+#pragma unroll
+      for (int s = 0; s < DT; ++s) qreg[sub][s] = 0.f;
+    }
+  }
+
+  f32x4 oacc[SUB][DB];
+  float m_run[SUB], l_run[SUB];
+#pragma unroll
+  for (int sub = 0; sub < SUB; ++sub) {
+    m_run[sub] = -1e30f;
+    l_run[sub] = 0.f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) oacc[sub][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int ntile = (N + KT - 1) / KT;
+  for (int kt = 0; kt < ntile; ++kt) {
+    __syncthreads();
+    // stage K, V (zero-filled beyond head_dim) and key info for keys kt*32 .. +31
+    for (int i = tid; i < KT * 4 * DT; i += 256) {
+      const int key = i / (4 * DT), e = i % (4 * DT);
+      const int kn = kt * KT + key;
+      float kv = 0.f, vv = 0.f;
+      if (kn < N) {
+        const Coord c = token_coord(D, ipl, ilat, ilon, kn);
+        if (e == 0) s_info[key] = pack_info(c);
+        if (c.src >= 0) {
+          kv = qkv_b[c.src * 3 * C + C + head * d + e];
+          vv = qkv_b[c.src * 3 * C + 2 * C + head * d + e];
+        } else {
+          kv = qkv_bias[C + head * d + e];
+          vv = qkv_bias[2 * C + head * d + e];
+        }
+      } else if (e == 0) {
+        s_info[key] = -1;
+      }
+      s_k[key * LDK + e] = kv;
+      s_v[key * LDV + e] = vv;
+    }
+    if (16 * DB > 4 * DT) {  // zero the pad columns of V (head_dim not a multiple of 16)
+      for (int i = tid; i < KT * (16 * DB - 4 * DT); i += 256) {
+        const int key = i / (16 * DB - 4 * DT), e = 4 * DT + i % (16 * DB - 4 * DT);
+        s_v[key * LDV + e] = 0.f;
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int sub = 0; sub < SUB; ++sub) {
+      // S^T[key][query] for the two 16-key blocks of the tile
+      f32x4 sc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        sc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < DT; ++s) sc[kb] = mfma16x16x4(s_k[(kb * 16 + j) * LDK + 4 * s + g], qreg[sub][s], sc[kb]);
+      }
+      // bias + mask: this lane's query is column j, its keys are rows 4g + r of each block
+      const int qi = qinfo[sub];
+      const int qpl = qi & 0xF, qlat = (qi >> 4) & 0xFF, qlon = (qi >> 12) & 0xFF, qreg_id = (qi >> 20) & 0x1F;
+      float mx = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ki = s_info[kb * 16 + 4 * g + r];
+          float v;
+          if (ki < 0) {
+            v = -1e30f;
+          } else {
+            const int kpl = ki & 0xF, klat = (ki >> 4) & 0xFF, klon = (ki >> 12) & 0xFF, kreg = (ki >> 20) & 0x1F;
+            int idx;
+            if (D.bias_mode == 0) {
+              idx = (qlat - klat + D.wlat - 1) * (2 * D.wlon - 1) + (qlon - klon + D.wlon - 1);
+            } else {
+              idx = ((qpl + kpl * D.wpl) * D.wlat * D.wlat + (qlat + klat * D.wlat)) * (2 * D.wlon - 1) +
+                    (qlon - klon + D.wlon - 1);
+            }
+            v = sc[kb][r] + s_tab[idx];
+            if (D.use_mask && kreg != qreg_id) v += -100.0f;
+          }
+          sc[kb][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[sub], mx);
+      const float alpha = __expf(m_run[sub] - m_new);
+      m_run[sub] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pexp = __expf(sc[kb][r] - m_new);
+          sc[kb][r] = pexp;
+          psum += pexp;
+        }
+      l_run[sub] = l_run[sub] * alpha + psum;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) oacc[sub][db] *= alpha;
+      // O^T[dim][query] += V^T[dim][key] P^T[key][query]; P^T rows (keys) = 4g + r = accumulator rows
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+            oacc[sub][db] = mfma16x16x4(s_v[(kb * 16 + 4 * g + r) * LDV + 16 * db + j], sc[kb][r], oacc[sub][db]);
+    }
+  }
+
+  // epilogue: normalise, transpose through LDS (reuse the K/V tile area) and store whole rows
+  __syncthreads();
+  float* s_o = s_k;  // [64*SUB queries][16*DB + 1]
+  constexpr int LDO = 16 * DB + 1;
+#pragma unroll
+  for (int sub = 0; sub < SUB; ++sub) {
+    float l = l_run[sub];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int ql = wave * (16 * SUB) + 16 * sub + j;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_o[ql * LDO + 16 * db + 4 * g + r] = oacc[sub][db][r] * inv;
+  }
+  __syncthreads();
+  float* out_b = out + (long long)b * L * C;
+  for (int i = tid; i < 64 * SUB * d; i += 256) {
+    const int ql = i / d, e = i % d;
+    const int qn = blockIdx.x * (64 * SUB) + ql;
+    if (qn < N) {
+      const long long dst = token_dest(D, ipl, ilat, ilon, qn);
+      if (dst >= 0) out_b[dst * C + head * d + e] = s_o[ql * LDO + e];
+    }
+  }
+}
+
+}  // namespace wattn
+}  // namespace dlwp
+
+using namespace dlwp;
+using namespace dlwp::wattn;
+
+template <int DT, int DB>
+static int32_t launch_wattn(const Desc& D, const float* qkv, const float* qkv_bias, const float* table, float* out,
+                            int batch, long long L, hipStream_t s) {
+  const int nwin = D.npl * D.nlat * D.nlon;
+  constexpr int KT = 32, LDK = 4 * DT + 2, LDV = 16 * DB + 4;
+  const bool big = D.N >= 512;
+  const int sub = big ? 2 : 1;
+  size_t lds = (size_t)(((D.table_rows + 3) & ~3) + KT * LDK + KT * LDV) * 4 + KT * 4;
+  const size_t epi = (size_t)(((D.table_rows + 3) & ~3)) * 4 + (size_t)64 * sub * (16 * DB + 1) * 4;
+  if (epi > lds) lds = epi;
+  DLWP_REQUIRE(lds <= 160 * 1024, DLWP_ERR_UNSUPPORTED, "window attention needs %zu bytes of LDS (bias table too large)", lds);
+  const dim3 grid((D.N + 64 * sub - 1) / (64 * sub), D.heads, batch * nwin);
+  if (big) {
+    if (lds > 48 * 1024)
+      DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_f32_kernel<DT, DB, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((window_attn_f32_kernel<DT, DB, 2>), grid, dim3(256), lds, s, D, qkv, qkv_bias, table, out, L);
+  } else {
+    if (lds > 48 * 1024)
+      DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_f32_kernel<DT, DB, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((window_attn_f32_kernel<DT, DB, 1>), grid, dim3(256), lds, s, D, qkv, qkv_bias, table, out, L);
+  }
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
+                                        const float* table, float* out, int32_t batch, void* stream) {
+  DLWP_REQUIRE(u && qkv && table && out, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0, DLWP_ERR_INVALID_ARGUMENT, "batch must be positive");
+  Desc D;
+  D.pl = u->grid[0]; D.lat = u->grid[1]; D.lon = u->grid[2];
+  D.wpl = u->window[0]; D.wlat = u->window[1]; D.wlon = u->window[2];
+  DLWP_REQUIRE(D.pl > 0 && D.lat > 0 && D.lon > 0 && D.wpl > 0 && D.wlat > 0 && D.wlon > 0, DLWP_ERR_INVALID_ARGUMENT,
+               "grid and window must be positive");
+  D.pad_f = u->pad_lead[0]; D.pad_t = u->pad_lead[1]; D.pad_l = u->pad_lead[2];
+  D.ppl = u->padded[0]; D.plat = u->padded[1]; D.plon = u->padded[2];
+  DLWP_REQUIRE(D.ppl % D.wpl == 0 && D.plat % D.wlat == 0 && D.plon % D.wlon == 0, DLWP_ERR_INVALID_ARGUMENT,
+               "padded grid (%d,%d,%d) is not a multiple of the window (%d,%d,%d)", D.ppl, D.plat, D.plon, D.wpl,
+               D.wlat, D.wlon);
+  DLWP_REQUIRE(D.ppl >= D.pl + D.pad_f && D.plat >= D.lat + D.pad_t && D.plon >= D.lon + D.pad_l,
+               DLWP_ERR_INVALID_ARGUMENT, "padded grid smaller than grid + leading pad");
+  D.npl = D.ppl / D.wpl; D.nlat = D.plat / D.wlat; D.nlon = D.plon / D.wlon;
+  for (int i = 0; i < 3; ++i) {
+    const int dim = i == 0 ? D.ppl : (i == 1 ? D.plat : D.plon);
+    D.sf[i] = ((u->shift_fwd[i] % dim) + dim) % dim;
+    D.sb[i] = ((u->shift_back[i] % dim) + dim) % dim;
+    D.b1[i] = u->mask_b1[i];
+    D.b2[i] = u->mask_b2[i];
+  }
+  D.use_mask = u->use_mask;
+  D.bias_mode = u->bias_mode;
+  D.heads = u->heads; D.d = u->head_dim; D.C = u->heads * u->head_dim;
+  D.N = D.wpl * D.wlat * D.wlon;
+  D.scale = u->scale;
+  DLWP_REQUIRE(D.wpl <= 16 && D.wlat <= 256 && D.wlon <= 256, DLWP_ERR_UNSUPPORTED, "window too large for the packed coordinates");
+  if (D.bias_mode == 0) {
+    DLWP_REQUIRE(D.wpl == 1, DLWP_ERR_INVALID_ARGUMENT, "Swin bias mode needs a 2-D window");
+    D.table_rows = (2 * D.wlat - 1) * (2 * D.wlon - 1);
+    D.types = 1;
+  } else {
+    D.table_rows = D.wpl * D.wpl * D.wlat * D.wlat * (2 * D.wlon - 1);
+    D.types = D.npl * D.nlat;
+  }
+  const bool padded = (D.ppl != D.pl) || (D.plat != D.lat) || (D.plon != D.lon);
+  DLWP_REQUIRE(!padded || qkv_bias, DLWP_ERR_INVALID_ARGUMENT, "padded windows need the qkv bias (zero-padded tokens carry it)");
+  DLWP_REQUIRE(D.d % 4 == 0 && D.d >= 4 && D.d <= 64, DLWP_ERR_UNSUPPORTED, "head_dim %d must be a multiple of 4 in [4,64]", D.d);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long L = (long long)D.pl * D.lat * D.lon;
+  const float* qb = qkv_bias ? qkv_bias : qkv;  // never dereferenced when nothing is padded
+  switch (D.d / 4) {
+#define DLWP_CASE(DT_) \
+  case DT_: return launch_wattn<DT_, (4 * DT_ + 15) / 16>(D, qkv, qb, table, out, batch, L, s);
+    DLWP_CASE(1) DLWP_CASE(2) DLWP_CASE(3) DLWP_CASE(4) DLWP_CASE(5) DLWP_CASE(6) DLWP_CASE(7) DLWP_CASE(8)
+    DLWP_CASE(9) DLWP_CASE(10) DLWP_CASE(11) DLWP_CASE(12) DLWP_CASE(13) DLWP_CASE(14) DLWP_CASE(15) DLWP_CASE(16)
+#undef DLWP_CASE
+    default: break;
+  }
+  return fail(DLWP_ERR_UNSUPPORTED, "head_dim %d not supported", D.d);
+}

@@ -29,6 +29,16 @@ class FNO2dDesc(ctypes.Structure):
     ]
 
 
+class WAttnDesc(ctypes.Structure):
+    """mirror of struct dlwp_wattn_desc (include/dlwp_hip.h)"""
+    _fields_ = [
+        ("grid", c_int32 * 3), ("padded", c_int32 * 3), ("pad_lead", c_int32 * 3), ("window", c_int32 * 3),
+        ("shift_fwd", c_int32 * 3), ("shift_back", c_int32 * 3), ("use_mask", c_int32),
+        ("mask_b1", c_int32 * 3), ("mask_b2", c_int32 * 3), ("bias_mode", c_int32),
+        ("heads", c_int32), ("head_dim", c_int32), ("scale", c_float),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/dlwp_hip.h declares
 SIGNATURES = {
     "dlwp_version": (c_int32, []),
@@ -50,6 +60,7 @@ SIGNATURES = {
                                                    c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "dlwp_spectral_conv2d_plan_destroy": (c_int32, [c_void_p]),
     "dlwp_spectral_conv2d_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "dlwp_window_attn_f32": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "dlwp_spectral_conv2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
 }
 

@@ -6,5 +6,8 @@ drop-in is a package that exports the same CLASS NAMES.  Put `dlwp_benchmark_amd
 `sys.path` as `models` or import from here directly.
 """
 from .fno import FNO2DModule
+from .pangu import PanguWeather
+from .spectral import SpectralConv2d
+from .swin import SwinTransformer
 
-__all__ = ["FNO2DModule"]
+__all__ = ["FNO2DModule", "PanguWeather", "SpectralConv2d", "SwinTransformer"]

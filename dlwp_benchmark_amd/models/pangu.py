@@ -1,0 +1,249 @@
+"""PanguWeather -- drop-in for reference models/panguweather/panguweather.py:366-535 (the 2-D variant
+the reference ships: one pressure "level", levels enter as channels) on MI355X, inference rollout.
+Same class name, constructor kwargs (:376-390), state-dict names/shapes (incl. the
+`earth_position_index` and `attn_mask` buffers) and forward signature.
+
+Per block, ZeroPad3d + roll + 3-D window partition + EarthAttention3D (bias gather from the
+[3312, types, nH] table, 0/-100 shift mask, softmax(QK^T)V) + window reverse + roll + crop3d
+(:285-316, :176-211, utils/*.py) are ONE HIP kernel (`dlwp_window_attn_f32`, bias_mode 1): pad, rolls,
+partition, mask and bias are index arithmetic; the `attn_mask` / `earth_position_index` buffers exist
+only for checkpoint compatibility.  Reference quirks reproduced: the level axis is zero-padded 1 -> 2
+and the padded tokens take part in the softmax (utils/pad.py:21-24); the forward roll shifts longitude
+by shift_lat while the reverse roll uses shift_lon (:291 vs :310).
+Linear / LayerNorm / (transposed) convolutions run through torch on the GPU (rocBLAS / MIOpen).
+"""
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import lib as _lib
+from .. import ops
+from ..rollout import rollout_into
+from ._base import HipBackbone
+from .swin import _Mlp
+
+
+def _pad3d(res, win):
+    """(left, right, top, bottom, front, back), utils/pad.py:4-34."""
+    out = [0] * 6
+    for slot, (n, w) in zip((4, 2, 0), zip(res, win)):
+        if n % w:
+            p = w - n % w
+            out[slot], out[slot + 1] = p // 2, p - p // 2
+    return tuple(out)
+
+
+def _earth_position_index(win):
+    wpl, wlat, wlon = win
+    zi, zj = torch.arange(wpl), -torch.arange(wpl) * wpl
+    hi, hj = torch.arange(wlat), -torch.arange(wlat) * wlat
+    w = torch.arange(wlon)
+    c1 = torch.stack(torch.meshgrid(zi, hi, w, indexing="ij")).flatten(1)
+    c2 = torch.stack(torch.meshgrid(zj, hj, w, indexing="ij")).flatten(1)
+    co = (c1[:, :, None] - c2[:, None, :]).permute(1, 2, 0).contiguous()
+    co[:, :, 2] += wlon - 1
+    co[:, :, 1] *= 2 * wlon - 1
+    co[:, :, 0] *= (2 * wlon - 1) * wlat * wlat
+    return co.sum(-1)
+
+
+def _shift_mask(res, win, shift):
+    """[nLon, nPl*nLat, N, N] of 0 / -100 (utils/shift_window_mask.py:37-73); state-dict buffer only."""
+    pl, lat, lon = res
+    wpl, wlat, wlon = win
+    spl, slat, slon = shift
+    ids = []
+    for n, w, s, ext in ((pl, wpl, spl, 0), (lat, wlat, slat, 0), (lon, wlon, slon, slon)):
+        p = torch.arange(n)
+        ids.append((p >= n + ext - w).long() + (p >= n + ext - s).long())
+    reg = (ids[0][:, None, None] * 3 + ids[1][None, :, None]) * 3 + ids[2][None, None, :]     # [pl, lat, lon]
+    reg = reg.view(pl // wpl, wpl, lat // wlat, wlat, lon // wlon, wlon).permute(4, 0, 2, 1, 3, 5)
+    reg = reg.reshape(lon // wlon, (pl // wpl) * (lat // wlat), wpl * wlat * wlon)
+    diff = reg.unsqueeze(2) != reg.unsqueeze(3)
+    return torch.where(diff, torch.tensor(-100.0), torch.tensor(0.0))
+
+
+class _EarthAttention3D(nn.Module):
+    def __init__(self, dim, pad_resolution, window_size, num_heads):
+        super().__init__()
+        self.window_size = tuple(window_size)
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        wpl, wlat, wlon = self.window_size
+        self.type_of_windows = (pad_resolution[0] // wpl) * (pad_resolution[1] // wlat)
+        self.earth_position_bias_table = nn.Parameter(
+            torch.zeros(wpl ** 2 * wlat ** 2 * (wlon * 2 - 1), self.type_of_windows, num_heads))
+        self.register_buffer("earth_position_index", _earth_position_index(self.window_size))
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _EarthSpecificBlock(nn.Module):
+    def __init__(self, dim, input_resolution, num_heads, window_size, shift_size):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.input_resolution = tuple(input_resolution)
+        self.window_size = tuple(window_size)
+        self.shift_size = tuple(shift_size)
+        self.norm1 = nn.LayerNorm(dim)
+        self.padding = _pad3d(self.input_resolution, self.window_size)
+        pl, lat, lon = self.input_resolution
+        p = self.padding
+        self.pad_resolution = (pl + p[4] + p[5], lat + p[2] + p[3], lon + p[0] + p[1])
+        self.attn = _EarthAttention3D(dim, self.pad_resolution, self.window_size, num_heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _Mlp(dim, int(dim * 4.0))
+        self.roll = bool(self.shift_size[0] and self.shift_size[1] and self.shift_size[2])
+        self.register_buffer("attn_mask", _shift_mask(self.pad_resolution, self.window_size, self.shift_size)
+                             if self.roll else None)
+
+    def forward(self, x):
+        ppl, plat, plon = self.pad_resolution
+        wpl, wlat, wlon = self.window_size
+        spl, slat, slon = self.shift_size
+        p = self.padding
+        if self.roll:
+            fwd, back = (spl, slat, slat), (spl, slat, slon)      # [sic] panguweather.py:291 vs :310
+        else:
+            fwd = back = (0, 0, 0)
+        spec = ops.WindowSpec(
+            grid=self.input_resolution, padded=self.pad_resolution, pad_lead=(p[4], p[2], p[0]),
+            window=self.window_size, shift_fwd=fwd, shift_back=back, use_mask=self.roll,
+            # slices of utils/shift_window_mask.py:55-57 (the longitude axis is laid out lon + shift_lon wide)
+            mask_b1=(ppl - wpl, plat - wlat, plon + slon - wlon) if self.roll else (ops.BIG,) * 3,
+            mask_b2=(ppl - spl, plat - slat, plon) if self.roll else (ops.BIG,) * 3,
+            bias_mode=1, heads=self.num_heads, head_dim=self.dim // self.num_heads, scale=self.attn.scale)
+        qkv = self.attn.qkv(self.norm1(x))
+        a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec)
+        x = x + self.attn.proj(a)
+        return x + self.mlp(self.norm2(x))
+
+
+class _BasicLayer(nn.Module):
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            _EarthSpecificBlock(dim, input_resolution, num_heads, window_size, (0, 0, 0) if i % 2 == 0 else (1, 3, 6))
+            for i in range(depth)])
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+
+class _DownSample(nn.Module):
+    def __init__(self, in_dim, input_resolution, output_resolution):
+        super().__init__()
+        self.linear = nn.Linear(in_dim * 4, in_dim * 2, bias=False)
+        self.norm = nn.LayerNorm(4 * in_dim)
+        self.input_resolution, self.output_resolution = tuple(input_resolution), tuple(output_resolution)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        pl, lat, lon = self.input_resolution
+        _, olat, olon = self.output_resolution
+        hp, wp = olat * 2 - lat, olon * 2 - lon
+        x = x.reshape(b, pl, lat, lon, c)
+        x = F.pad(x, (0, 0, wp // 2, wp - wp // 2, hp // 2, hp - hp // 2))
+        x = x.reshape(b, pl, olat, 2, olon, 2, c).permute(0, 1, 2, 4, 3, 5, 6).reshape(b, pl * olat * olon, 4 * c)
+        return self.linear(self.norm(x))
+
+
+class _UpSample(nn.Module):
+    def __init__(self, in_dim, out_dim, input_resolution, output_resolution):
+        super().__init__()
+        self.linear1 = nn.Linear(in_dim, out_dim * 4, bias=False)
+        self.linear2 = nn.Linear(out_dim, out_dim, bias=False)
+        self.norm = nn.LayerNorm(out_dim)
+        self.input_resolution, self.output_resolution = tuple(input_resolution), tuple(output_resolution)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        pl, lat, lon = self.input_resolution
+        _, olat, olon = self.output_resolution
+        x = self.linear1(x)
+        x = x.reshape(b, pl, lat, lon, 2, 2, c // 2).permute(0, 1, 2, 4, 3, 5, 6).reshape(b, pl, lat * 2, lon * 2, -1)
+        ph, pw = lat * 2 - olat, lon * 2 - olon
+        x = x[:, :pl, ph // 2: 2 * lat - (ph - ph // 2), pw // 2: 2 * lon - (pw - pw // 2), :]
+        x = x.reshape(b, -1, x.shape[-1])
+        return self.linear2(self.norm(x))
+
+
+class _PatchEmbed2D(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.img_size, self.patch_size = tuple(img_size), tuple(patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+
+    def forward(self, x):
+        (h, w), (ph, pw) = self.img_size, self.patch_size
+        pt = pb = pl = pr = 0
+        if h % ph:
+            q = ph - h % ph
+            pt, pb = q // 2, q - q // 2
+        if w % pw:
+            q = pw - w % pw
+            pl, pr = q // 2, q - q // 2
+        return self.proj(F.pad(x, (pl, pr, pt, pb)))
+
+
+class _PatchRecovery2D(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, out_chans):
+        super().__init__()
+        self.img_size = tuple(img_size)
+        self.conv = nn.ConvTranspose2d(in_chans, out_chans, tuple(patch_size), tuple(patch_size))
+
+    def forward(self, x):
+        out = self.conv(x)
+        hh, ww = out.shape[2], out.shape[3]
+        hp, wp = hh - self.img_size[0], ww - self.img_size[1]
+        return out[:, :, hp // 2: hh - (hp - hp // 2), wp // 2: ww - (wp - wp // 2)]
+
+
+class PanguWeather(HipBackbone):
+    def __init__(self, constant_channels: int = 4, prescribed_channels: int = 0, prognostic_channels: int = 1,
+                 embed_dim: int = 192, num_heads: tuple = (6, 12, 12, 6), window_size: tuple = (2, 6, 12),
+                 patch_size: tuple = (4, 4), n_lat: int = 721, n_lon: int = 1440, context_size: int = 1, **kwargs):
+        super().__init__()
+        self.context_size = int(context_size)
+        num_heads, window_size, patch_size = list(num_heads), tuple(window_size), tuple(patch_size)
+        in_chans = constant_channels + (prescribed_channels + prognostic_channels) * context_size
+        self.patchembed2d = _PatchEmbed2D((n_lat, n_lon), patch_size, in_chans, embed_dim)
+        res = (1, n_lat // patch_size[0], n_lon // patch_size[1])
+        res2 = (1, res[1] // 2, res[2] // 2)
+        self.layer1 = _BasicLayer(embed_dim, res, 2, num_heads[0], window_size)
+        self.downsample = _DownSample(embed_dim, res, res2)
+        self.layer2 = _BasicLayer(embed_dim * 2, res2, 6, num_heads[1], window_size)
+        self.layer3 = _BasicLayer(embed_dim * 2, res2, 6, num_heads[2], window_size)
+        self.upsample = _UpSample(embed_dim * 2, embed_dim, res2, res)
+        self.layer4 = _BasicLayer(embed_dim, res, 2, num_heads[3], window_size)
+        self.patchrecovery2d = _PatchRecovery2D((n_lat, n_lon), patch_size, 2 * embed_dim, prognostic_channels)
+
+    def one_step(self, x: torch.Tensor) -> torch.Tensor:
+        """panguweather.py:512-535 (`forward_one_step`)."""
+        x = self.patchembed2d(x)
+        b, c, lat, lon = x.shape
+        x = x.reshape(b, c, -1).transpose(1, 2)
+        x = self.layer1(x)
+        skip = x
+        x = self.layer3(self.layer2(self.downsample(x)))
+        x = self.layer4(self.upsample(x))
+        out = torch.cat([x, skip], dim=-1).transpose(1, 2).reshape(b, -1, lat, lon)
+        return self.patchrecovery2d(out)
+
+    def rollout_into(self, out, constants, prescribed, prognostic, step_begin=0, step_end=-1):
+        return rollout_into(self.one_step, self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)
+
+    def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
+        with torch.no_grad():
+            b, t, cg, h, w = prognostic.shape
+            if t <= self.context_size:
+                raise _lib.DlwpError(f"need more than context_size={self.context_size} frames, got {t}")
+            out = torch.empty(b, t - self.context_size, cg, h, w, device=prognostic.device, dtype=torch.float32)
+            self.rollout_into(out, constants, prescribed, prognostic)
+        return out

@@ -142,6 +142,43 @@ int32_t dlwp_spectral_conv2d_f32(const dlwp_spectral_plan* plan, const float* x_
                                  int32_t batch, void* workspace_dev, size_t workspace_bytes,
                                  void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused (shifted-)window attention, fp32.  Replaces everything between the qkv Linear and the proj
+ * Linear of a transformer block:
+ *   Swin : models/swintransformer/swin_transformer.py:217-251 (pad, roll, window_partition,
+ *          WindowAttention.forward :122-154 without its two Linears, window_reverse, roll, crop) and
+ *          the per-call shift-mask build :383-401
+ *   Pangu: models/panguweather/panguweather.py:285-316 + EarthAttention3D.forward :176-211 without
+ *          its two Linears, utils/shift_window_mask.py, utils/earth_position_index.py, utils/pad.py,
+ *          utils/crop.py
+ * qkv_dev  [B, L, 3, heads, head_dim]  output of the qkv Linear on the un-padded token sequence,
+ *          L = grid[0]*grid[1]*grid[2] (a 2-D model uses grid[0] = window[0] = 1)
+ * qkv_bias_dev [3*heads*head_dim] or NULL: value of q,k,v at zero-padded tokens (the reference
+ *          pads before the Linear); required when padded != grid
+ * table_dev  bias_mode 0: relative_position_bias_table [(2Wh-1)(2Ww-1), heads]
+ *            bias_mode 1: earth_position_bias_table [wpl^2*wlat^2*(2wlon-1), types, heads],
+ *                         types = (padded[0]/window[0]) * (padded[1]/window[1])
+ * out_dev  [B, L, heads*head_dim] in the input token order (window reverse / roll back / crop done)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dlwp_wattn_desc {
+  int32_t grid[3];        /* un-padded (pl, lat, lon)                                          */
+  int32_t padded[3];      /* padded grid, multiple of window                                   */
+  int32_t pad_lead[3];    /* zeros added in front / top / left                                 */
+  int32_t window[3];
+  int32_t shift_fwd[3];   /* torch.roll(x, shifts=-shift_fwd) before partitioning              */
+  int32_t shift_back[3];  /* torch.roll(y, shifts=+shift_back) after window_reverse            */
+  int32_t use_mask;       /* add the 0/-100 region mask                                        */
+  int32_t mask_b1[3];     /* region id along a dim = (p >= mask_b1) + (p >= mask_b2), p being  */
+  int32_t mask_b2[3];     /*   the coordinate in the shifted, padded frame                     */
+  int32_t bias_mode;      /* 0 Swin relative position, 1 Pangu earth-specific                  */
+  int32_t heads, head_dim;
+  float scale;            /* qk scale (head_dim ** -0.5 unless overridden)                     */
+} dlwp_wattn_desc;
+
+int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* desc, const float* qkv_dev,
+                             const float* qkv_bias_dev, const float* table_dev, float* out_dev,
+                             int32_t batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,3 +51,27 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports oracle"
+
+
+def test_state_dicts_match_reference_layout():
+    """Product modules expose exactly the reference's state-dict keys / shapes / dtypes (recorded
+    from the real reference classes in the golden fixtures): checkpoints load unchanged."""
+    import json
+
+    import dlwp_benchmark_amd.models as M
+    from helpers import load_golden
+    from oracle.make_golden import MODEL_CASES
+
+    names = {"swin": "SwinTransformer", "pangu": "PanguWeather", "afno": "FourCastNet", "unet": "UNet",
+             "convlstm": "ConvLSTM"}
+    checked = 0
+    for tag, (family, cfg, _, _) in MODEL_CASES.items():
+        if not hasattr(M, names[family]):
+            continue
+        g = load_golden(f"model_{tag}")
+        want = {k: (tuple(s), d) for k, s, d in json.loads(str(g["state_spec"]))}
+        m = getattr(M, names[family])(**cfg)
+        got = {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()}
+        assert got == want, (tag, sorted(set(want) ^ set(got))[:6])
+        checked += 1
+    assert checked >= 3
