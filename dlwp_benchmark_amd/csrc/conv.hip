@@ -1,0 +1,159 @@
+// Cylinder-padded 3x3 convolution stack pieces for the U-Net / ConvLSTM backbones (gfx950).
+//
+// Replaces, per layer, `CylinderPad(1)` + `Conv2d(k=3, padding=0)` + activation
+// (reference utils/utils.py:11-26; models/unet/unet.py:456-470, :512-525; models/convlstm/convlstm.py:47-55,
+// :148-157) -- and, for the skip connections and the ConvLSTM cell, the preceding `torch.cat`
+// (unet.py:553; convlstm.py:94): the input may be given as TWO channel segments.
+// Direct convolution: one workgroup = one 8x32 output tile of one sample; the (8+2)x(32+2) input halo
+// tile of a chunk of input channels is staged in LDS with the cylinder rule applied at load time
+// (longitude wraps, latitude pads with zeros), every thread owns one pixel and accumulates a chunk of
+// output channels with weights broadcast from LDS; bias + activation fused in the epilogue.
+#include "common.hpp"
+
+namespace dlwp {
+namespace conv {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_RELU = 3, ACT_SILU = 4 };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_GELU: return gelu_erf(v);
+    case ACT_TANH: return tanhf(v);
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SILU: return v / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+constexpr int TH = 8, TW = 32, CI_CHUNK = 8, CO_CHUNK = 16;
+
+struct Params {
+  const float* x0; int c0;   // first input segment [B][c0][H][W]
+  const float* x1; int c1;   // second segment or null
+  const float* w;            // [Cout][c0+c1][3][3]
+  const float* bias;         // [Cout] or null
+  float* y;                  // [B][Cout][H][W]
+  int B, H, W, Cout, act;
+};
+
+__global__ __launch_bounds__(256) void conv3x3_cyl_kernel(const Params p) {
+  __shared__ float s_in[CI_CHUNK][TH + 2][TW + 2];
+  __shared__ float s_w[CO_CHUNK][CI_CHUNK][9];
+  const int tid = threadIdx.x;
+  const int tx = tid % TW, ty = tid / TW;
+  const int tiles_w = (p.W + TW - 1) / TW;
+  const int w0 = (blockIdx.x % tiles_w) * TW, h0 = (blockIdx.x / tiles_w) * TH;
+  const int b = blockIdx.y;
+  const int cin = p.c0 + p.c1;
+  const int ow = w0 + tx, oh = h0 + ty;
+  const long long HW = (long long)p.H * p.W;
+  for (int co0 = 0; co0 < p.Cout; co0 += CO_CHUNK) {
+    float acc[CO_CHUNK];
+#pragma unroll
+    for (int k = 0; k < CO_CHUNK; ++k) acc[k] = 0.f;
+    for (int ci0 = 0; ci0 < cin; ci0 += CI_CHUNK) {
+      __syncthreads();
+      for (int i = tid; i < CI_CHUNK * (TH + 2) * (TW + 2); i += 256) {
+        const int ci = i / ((TH + 2) * (TW + 2));
+        const int rem = i % ((TH + 2) * (TW + 2));
+        const int r = rem / (TW + 2), cc = rem % (TW + 2);
+        const int c = ci0 + ci;
+        const int ih = h0 + r - 1;
+        int iw = w0 + cc - 1;
+        float v = 0.f;
+        if (c < cin && ih >= 0 && ih < p.H && iw >= -1 && iw <= p.W) {
+          iw = iw < 0 ? iw + p.W : (iw >= p.W ? iw - p.W : iw);   // circular longitude
+          const float* src = c < p.c0 ? p.x0 + ((long long)b * p.c0 + c) * HW
+                                      : p.x1 + ((long long)b * p.c1 + (c - p.c0)) * HW;
+          v = src[(long long)ih * p.W + iw];
+        }
+        (&s_in[0][0][0])[i] = v;
+      }
+      for (int i = tid; i < CO_CHUNK * CI_CHUNK * 9; i += 256) {
+        const int k = i / (CI_CHUNK * 9), rem = i % (CI_CHUNK * 9);
+        const int ci = rem / 9, t = rem % 9;
+        const int co = co0 + k, c = ci0 + ci;
+        (&s_w[0][0][0])[i] = (co < p.Cout && c < cin) ? p.w[((long long)co * cin + c) * 9 + t] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ci = 0; ci < CI_CHUNK; ++ci) {
+        float v[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) v[r * 3 + cc] = s_in[ci][ty + r][tx + cc];
+#pragma unroll
+        for (int k = 0; k < CO_CHUNK; ++k)
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[k] = fmaf(v[t], s_w[k][ci][t], acc[k]);
+      }
+    }
+    if (ow < p.W && oh < p.H) {
+#pragma unroll
+      for (int k = 0; k < CO_CHUNK; ++k) {
+        const int co = co0 + k;
+        if (co < p.Cout) {
+          float v = acc[k] + (p.bias ? p.bias[co] : 0.f);
+          p.y[((long long)b * p.Cout + co) * HW + (long long)oh * p.W + ow] = apply_act(v, p.act);
+        }
+      }
+    }
+  }
+}
+
+// ConvLSTM cell gate math (convlstm.py:96-109): gates [B][4*hid][H][W] = (netin, igate, fgate, ogate)
+__global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __restrict__ gates,
+                                                             const float* __restrict__ c_prev, float* __restrict__ h_out,
+                                                             float* __restrict__ c_out, int hid, long long HW,
+                                                             long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i % HW;
+    const long long bc = i / HW;
+    const int ch = (int)(bc % hid);
+    const long long b = bc / hid;
+    const float* gb = gates + (b * 4 * hid) * HW + pix;
+    const float netin = gb[(long long)ch * HW];
+    const float ig = gb[(long long)(hid + ch) * HW];
+    const float fg = gb[(long long)(2 * hid + ch) * HW];
+    const float og = gb[(long long)(3 * hid + ch) * HW];
+    const float sig_i = 1.f / (1.f + __expf(-ig)), sig_f = 1.f / (1.f + __expf(-fg)), sig_o = 1.f / (1.f + __expf(-og));
+    const float c = sig_f * c_prev[i] + sig_i * tanhf(netin);
+    c_out[i] = c;
+    h_out[i] = sig_o * tanhf(c);
+  }
+}
+
+}  // namespace conv
+}  // namespace dlwp
+
+using namespace dlwp;
+
+extern "C" int32_t dlwp_conv3x3_cyl_f32(const float* x0, int32_t c0, const float* x1, int32_t c1, const float* weight,
+                                        const float* bias, float* y, int32_t batch, int32_t H, int32_t W, int32_t cout,
+                                        int32_t act, void* stream) {
+  DLWP_REQUIRE(x0 && weight && y, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0 && H > 0 && W > 1 && c0 > 0 && cout > 0 && c1 >= 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
+  DLWP_REQUIRE(c1 == 0 || x1, DLWP_ERR_INVALID_ARGUMENT, "second segment pointer missing");
+  DLWP_REQUIRE(act >= 0 && act <= 4, DLWP_ERR_INVALID_ARGUMENT, "unknown activation %d", act);
+  conv::Params p;
+  p.x0 = x0; p.c0 = c0; p.x1 = x1; p.c1 = c1; p.w = weight; p.bias = bias; p.y = y;
+  p.B = batch; p.H = H; p.W = W; p.Cout = cout; p.act = act;
+  const int tiles = ((W + conv::TW - 1) / conv::TW) * ((H + conv::TH - 1) / conv::TH);
+  hipLaunchKernelGGL(conv::conv3x3_cyl_kernel, dim3(tiles, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_convlstm_gates_f32(const float* gates, const float* c_prev, float* h_out, float* c_out,
+                                           int32_t batch, int32_t hidden, int32_t H, int32_t W, void* stream) {
+  DLWP_REQUIRE(gates && c_prev && h_out && c_out, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0 && hidden > 0 && H > 0 && W > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
+  const long long HW = (long long)H * W, total = (long long)batch * hidden * HW;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(conv::convlstm_gates_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), gates, c_prev, h_out, c_out, hidden, HW, total);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}

@@ -2,12 +2,16 @@
 
 The reference scripts resolve a backbone with `from models import *` followed by
 `eval(cfg.model.type)(**cfg.model)` (scripts/train.py:18,54; scripts/evaluate.py:34,140), so the
-drop-in is a package that exports the same CLASS NAMES.  Put `dlwp_benchmark_amd/` in front of
-`sys.path` as `models` or import from here directly.
+drop-in is a package that exports the same CLASS NAMES (live names of :6-12 plus the commented
+FNO2DModule / ConvLSTM of :4-5 that the north star covers).  Put this package in front of `sys.path`
+as `models` or import from here directly.
 """
 from .fno import FNO2DModule
+from .fourcastnet import AFNONet, FourCastNet
 from .pangu import PanguWeather
 from .spectral import SpectralConv2d
 from .swin import SwinTransformer
+from .unet import ConvLSTM, UNet
 
-__all__ = ["FNO2DModule", "PanguWeather", "SpectralConv2d", "SwinTransformer"]
+__all__ = ["FNO2DModule", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "UNet",
+           "ConvLSTM"]

@@ -1,0 +1,128 @@
+"""FourCastNet (= AFNONet) -- drop-in for reference models/fourcastnet/fourcastnet.py:214-361,
+registered as `FourCastNet` like the reference registry (models/__init__.py:6).  Same constructor
+kwargs (:215-234), state-dict names (`patch_embed.proj`, `pos_embed`, `blocks.{i}.{norm1,filter.{w1,b1,w2,b2},
+norm2,mlp.{fc1,fc2}}`, the unused `norm`, `head`) and forward signature.
+
+Per block the AFNO2D frequency-domain work (:87-121: four full-size zero buffers, slice-assigns, eight
+einsums, ReLU, softshrink) is ONE HIP kernel (`dlwp_afno2d_mix_f32`) between an rfft2 and an irfft2
+(currently torch.fft = rocFFT); LayerNorm / MLP / patch embedding / head run through torch on the GPU.
+The rollout is device resident and does NOT reproduce the reference's crash on the second step
+(`.to()` on a list, :336-340) nor its per-step `.cpu()` (:359).
+"""
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import lib as _lib
+from .. import ops
+from ..rollout import rollout_into
+from ._base import HipBackbone
+from .swin import _Mlp
+
+
+class AFNO2D(nn.Module):
+    def __init__(self, hidden_size, num_blocks=8, sparsity_threshold=0.01, hard_thresholding_fraction=1,
+                 hidden_size_factor=1):
+        super().__init__()
+        if hidden_size % num_blocks:
+            raise ValueError(f"hidden_size {hidden_size} should be divisble by num_blocks {num_blocks}")
+        if hidden_size_factor != 1:
+            raise NotImplementedError("hidden_size_factor != 1 is not used by the reference")
+        self.hidden_size, self.num_blocks = hidden_size, num_blocks
+        self.block_size = hidden_size // num_blocks
+        self.sparsity_threshold = sparsity_threshold
+        self.hard_thresholding_fraction = hard_thresholding_fraction
+        bs = self.block_size
+        self.w1 = nn.Parameter(0.02 * torch.randn(2, num_blocks, bs, bs))
+        self.b1 = nn.Parameter(0.02 * torch.randn(2, num_blocks, bs))
+        self.w2 = nn.Parameter(0.02 * torch.randn(2, num_blocks, bs, bs))
+        self.b2 = nn.Parameter(0.02 * torch.randn(2, num_blocks, bs))
+
+    def forward(self, x):
+        """x [B, H, W, C] -> irfft2(mix(rfft2(x))) + x   (fourcastnet.py:78-127)"""
+        b, h, w, c = x.shape
+        xf = torch.fft.rfft2(x, dim=(1, 2), norm="ortho")
+        yf = ops.afno2d_mix(xf, self.w1, self.b1, self.w2, self.b2, self.num_blocks, self.sparsity_threshold,
+                            self.hard_thresholding_fraction)
+        return torch.fft.irfft2(yf, s=(h, w), dim=(1, 2), norm="ortho") + x
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, mlp_ratio, num_blocks, sparsity_threshold, hard_thresholding_fraction):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.filter = AFNO2D(dim, num_blocks, sparsity_threshold, hard_thresholding_fraction)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        x = self.filter(self.norm1(x)) + x          # double skip (:186-189)
+        return self.mlp(self.norm2(x)) + x
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.img_size, self.patch_size = tuple(img_size), tuple(patch_size)
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+
+    def forward(self, x):
+        if tuple(x.shape[2:]) != self.img_size:
+            raise _lib.DlwpError(f"Input image size {tuple(x.shape[2:])} doesn't match model {self.img_size}")
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class FourCastNet(HipBackbone):
+    def __init__(self, img_height=720, img_width=1440, patch_size=(16, 16), constant_channels: int = 4,
+                 prescribed_channels: int = 0, prognostic_channels: int = 1, filter="AFNO2D", embed_dim=768, depth=12,
+                 mlp_ratio=4., drop_rate=0., drop_path_rate=0., num_blocks=16, sparsity_threshold=0.01,
+                 hard_thresholding_fraction=1.0, context_size: int = 1, use_pos_embed: bool = True, **kwargs):
+        super().__init__()
+        if filter != "AFNO2D":
+            raise NotImplementedError(f"filter {filter!r}: only the in-tree AFNO2D filter is on the hot path")
+        self.img_size = (int(img_height), int(img_width))
+        self.patch_size = tuple(int(p) for p in patch_size)
+        self.context_size = int(context_size)
+        self.embed_dim, self.out_chans, self.use_pos_embed = embed_dim, prognostic_channels, use_pos_embed
+        in_chans = constant_channels + (prescribed_channels + prognostic_channels) * context_size
+        self.patch_embed = _PatchEmbed(self.img_size, self.patch_size, in_chans, embed_dim)
+        if use_pos_embed:
+            self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+        self.h, self.w = self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1]
+        self.blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio, num_blocks, sparsity_threshold,
+                                            hard_thresholding_fraction) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)   # in the reference state dict, never applied (:283-293)
+        self.head = nn.Linear(embed_dim, self.out_chans * self.patch_size[0] * self.patch_size[1], bias=False)
+
+    def one_step(self, x: torch.Tensor) -> torch.Tensor:
+        b = x.shape[0]
+        x = self.patch_embed(x)
+        if self.use_pos_embed:
+            x = x + self.pos_embed
+        x = x.reshape(b, self.h, self.w, self.embed_dim)
+        for blk in self.blocks:
+            x = blk(x)
+        x = self.head(x)
+        p1, p2 = self.patch_size
+        return x.view(b, self.h, self.w, p1, p2, self.out_chans).permute(0, 5, 1, 3, 2, 4).reshape(
+            b, self.out_chans, self.h * p1, self.w * p2)
+
+    def rollout_into(self, out, constants, prescribed, prognostic, step_begin=0, step_end=-1):
+        return rollout_into(self.one_step, self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)
+
+    def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
+        with torch.no_grad():
+            b, t, cg, h, w = prognostic.shape
+            if t <= self.context_size:
+                raise _lib.DlwpError(f"need more than context_size={self.context_size} frames, got {t}")
+            out = torch.empty(b, t - self.context_size, cg, h, w, device=prognostic.device, dtype=torch.float32)
+            self.rollout_into(out, constants, prescribed, prognostic)
+        return out
+
+
+AFNONet = FourCastNet

@@ -1,0 +1,228 @@
+"""UNet (classic, equirectangular) and ConvLSTM -- drop-ins for reference models/unet/unet.py:274-383 +
+:429-555 and models/convlstm/convlstm.py:114-251 on MI355X (inference rollout).  Same class names,
+constructor kwargs, `nn.Sequential` index layout (so state-dict keys match: `encoder.layers.{l}.{k}`,
+`decoder.layers.{l}.{k}`, `decoder.output_layer`; `encoder.{1,4,7}`, `clstm.{i}.conv.1`, `decoder.1`) and
+forward signature.
+
+Every `CylinderPad(1) -> Conv2d(3x3) -> activation` triple is ONE HIP kernel (`dlwp_conv3x3_cyl_f32`:
+halo staged in LDS with the wrap/zero rule applied at load time, bias + activation in the epilogue); the
+skip-connection `torch.cat` (unet.py:553) and the ConvLSTM `cat((x, h_prev))` (convlstm.py:94) are folded
+into the kernel's two-segment input; the LSTM gate math (convlstm.py:96-109) is one fused kernel.
+AvgPool / ConvTranspose2d(2x2, s2) / the 1x1 head go through torch on the GPU.
+
+Reference defect NOT reproduced: the shipped UNet encoder pads twice (CylinderPad(1) AND padding=1,
+unet.py:456-462) and crashes on the first skip concat; this mirror uses the consistent `padding=0`
+semantics the decoder (:512-518) and ConvLSTM use -- the same workaround the oracle fixtures were
+generated with.
+"""
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import lib as _lib
+from .. import ops
+from ..rollout import rollout_into
+from ._base import HipBackbone
+
+
+class CylinderPad(nn.Module):
+    """Placeholder keeping the reference's Sequential indices (utils/utils.py:11-26); the padding
+    itself happens inside dlwp_conv3x3_cyl_f32."""
+
+    def __init__(self, padding: int = 1):
+        super().__init__()
+        self.p = padding
+
+
+def _resolve_activation(activation):
+    if isinstance(activation, str):
+        name = activation
+        for key, mod in (("GELU", nn.GELU), ("Tanh", nn.Tanh), ("LeakyReLU", None), ("ReLU", nn.ReLU), ("SiLU", nn.SiLU)):
+            if key in name:
+                if mod is None:
+                    break
+                return mod()
+        raise _lib.DlwpError(f"activation {activation!r} has no fused kernel (supported: GELU, Tanh, ReLU, SiLU)")
+    return activation
+
+
+def _run_stack(seq: nn.Sequential, x, skip=None):
+    """Executes a reference-shaped Sequential of [AvgPool] (CylinderPad, Conv2d, act)* [ConvTranspose2d]
+    with each (pad, conv, act) triple fused into one kernel call; `skip` is concatenated in front
+    of x for the first conv (torch.cat([skip, x], 1), unet.py:553)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, CylinderPad):
+            conv = mods[i + 1]
+            act = 0
+            step = 2
+            if i + 2 < len(mods) and not isinstance(mods[i + 2], (CylinderPad, nn.Conv2d, nn.ConvTranspose2d, nn.AvgPool2d)):
+                act = ops.act_code(mods[i + 2])
+                step = 3
+            if skip is not None:
+                x = ops.conv3x3_cyl(skip, conv.weight, conv.bias, act, x1=x)
+                skip = None
+            else:
+                x = ops.conv3x3_cyl(x, conv.weight, conv.bias, act)
+            i += step
+        else:
+            if skip is not None:
+                x = torch.cat([skip, x], dim=1)
+                skip = None
+            x = m(x)
+            i += 1
+    return x
+
+
+class _UNetEncoder(nn.Module):
+    def __init__(self, in_channels, hidden_channels, n_convolutions, activation):
+        super().__init__()
+        layers = []
+        channels = [in_channels] + list(hidden_channels)
+        for c_idx in range(len(channels) - 1):
+            layer = []
+            c_in, c_out = channels[c_idx], channels[c_idx + 1]
+            if c_idx > 0:
+                layer.append(nn.AvgPool2d(kernel_size=2, stride=2, padding=0))
+            n_convs = n_convolutions // 2 if c_idx == len(hidden_channels) - 1 else n_convolutions
+            for n_conv in range(n_convs):
+                layer += [CylinderPad(1), nn.Conv2d(c_in if n_conv == 0 else c_out, c_out, kernel_size=3, padding=0),
+                          activation]
+            layers.append(nn.Sequential(*layer))
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x):
+        outs = []
+        for layer in self.layers:
+            x = _run_stack(layer, x)
+            outs.append(x)
+        return outs
+
+
+class _UNetDecoder(nn.Module):
+    def __init__(self, hidden_channels, out_channels, n_convolutions, activation):
+        super().__init__()
+        hidden = list(hidden_channels)[::-1]
+        layers = []
+        c_out = hidden[0]
+        for c_idx in range(len(hidden)):
+            layer = []
+            c_in = c_out = hidden[c_idx]
+            n_convs = n_convolutions // 2 if c_idx == 0 else n_convolutions
+            for n_conv in range(n_convs):
+                c_in_ = c_in if c_idx == 0 else 2 * hidden[c_idx]
+                layer += [CylinderPad(1), nn.Conv2d(c_in_ if n_conv == 0 else c_out, c_out, kernel_size=3, padding=0),
+                          activation]
+            if c_idx < len(hidden) - 1:
+                layer.append(nn.ConvTranspose2d(c_out, hidden[c_idx + 1], kernel_size=2, stride=2))
+            layers.append(nn.Sequential(*layer))
+        self.layers = nn.ModuleList(layers)
+        self.output_layer = nn.Conv2d(c_out, out_channels, kernel_size=1)
+
+    def forward(self, x, skips):
+        for l_idx, layer in enumerate(self.layers):
+            x = _run_stack(layer, x, skip=skips[l_idx] if l_idx > 0 else None)
+        return self.output_layer(x)
+
+
+class UNet(HipBackbone):
+    def __init__(self, constant_channels: int = 4, prescribed_channels: int = 0, prognostic_channels: int = 1,
+                 hidden_channels: list = [8, 16, 32], n_convolutions: int = 2, activation=nn.GELU(),
+                 context_size: int = 1, mesh: str = "equirectangular", **kwargs):
+        super().__init__()
+        if mesh != "equirectangular":
+            raise NotImplementedError("HEALPix variant is a 'next' row (SURVEY.md 8f f3)")
+        activation = _resolve_activation(activation)
+        ops.act_code(activation)  # fail early if there is no fused kernel for it
+        self.context_size = int(context_size)
+        in_channels = constant_channels + (prescribed_channels + prognostic_channels) * context_size
+        self.encoder = _UNetEncoder(in_channels, list(hidden_channels), n_convolutions, activation)
+        self.decoder = _UNetDecoder(list(hidden_channels), prognostic_channels, n_convolutions, activation)
+
+    def one_step(self, x):
+        enc = self.encoder(x)
+        return self.decoder(x=enc[-1], skips=enc[::-1])
+
+    def rollout_into(self, out, constants, prescribed, prognostic, step_begin=0, step_end=-1):
+        return rollout_into(self.one_step, self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)
+
+    def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
+        with torch.no_grad():
+            b, t, cg, h, w = prognostic.shape
+            if t <= self.context_size:
+                raise _lib.DlwpError(f"need more than context_size={self.context_size} frames, got {t}")
+            out = torch.empty(b, t - self.context_size, cg, h, w, device=prognostic.device, dtype=torch.float32)
+            self.rollout_into(out, constants, prescribed, prognostic)
+        return out
+
+
+class _ConvLSTMCell(nn.Module):
+    def __init__(self, input_size, hidden_size, bias=True):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.conv = nn.Sequential(CylinderPad(1), nn.Conv2d(input_size + hidden_size, hidden_size * 4, kernel_size=3,
+                                                            stride=1, padding=0, bias=bias))
+
+
+class ConvLSTM(HipBackbone):
+    def __init__(self, batch_size: int = 16, constant_channels: int = 4, prescribed_channels: int = 0,
+                 prognostic_channels: int = 1, hidden_sizes: list = [16, 16], height: int = 32, width: int = 64,
+                 device=None, bias: bool = True, context_size: int = 1, mesh: str = "equirectangular", **kwargs):
+        super().__init__()
+        if mesh != "equirectangular":
+            raise NotImplementedError("HEALPix variant is a 'next' row (SURVEY.md 8f f3)")
+        self.hidden_sizes = list(hidden_sizes)
+        self.context_size = int(context_size)
+        in_size = constant_channels + prescribed_channels + prognostic_channels
+        h0 = self.hidden_sizes[0]
+        self.encoder = nn.Sequential(
+            CylinderPad(1), nn.Conv2d(in_size, h0, kernel_size=3, padding=0), nn.Tanh(),
+            CylinderPad(1), nn.Conv2d(h0, h0, kernel_size=3, padding=0), nn.Tanh(),
+            CylinderPad(1), nn.Conv2d(h0, h0, kernel_size=3, padding=0))
+        self.clstm = nn.Sequential(*[_ConvLSTMCell(hs, hs, bias) for hs in self.hidden_sizes])
+        self.decoder = nn.Sequential(CylinderPad(1), nn.Conv2d(self.hidden_sizes[-1], prognostic_channels, kernel_size=3,
+                                                               padding=0))
+
+    def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        """convlstm.py:210-251: loop from t = 0, teacher forcing while t < context_size, (h, c) carried
+        across steps, outputs[context_size:] returned.  The states live in local tensors instead of
+        module attributes (:108-109), so the module is re-entrant."""
+        constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
+        with torch.no_grad():
+            b, t_total, cg, hgt, wid = prognostic.shape
+            ctx = self.context_size
+            if t_total <= ctx:
+                raise _lib.DlwpError(f"need more than context_size={ctx} frames, got {t_total}")
+            dev = prognostic.device
+            hs = [torch.zeros(b, n, hgt, wid, device=dev) for n in self.hidden_sizes]
+            cs = [torch.zeros(b, n, hgt, wid, device=dev) for n in self.hidden_sizes]
+            out = torch.empty(b, t_total - ctx, cg, hgt, wid, device=dev, dtype=torch.float32)
+            prev = None
+            for t in range(t_total):
+                prog_t = prognostic[:, t] if t < ctx else prev
+                parts = []
+                if constants is not None:
+                    parts.append(constants[:, 0])
+                if prescribed is not None:
+                    parts.append(prescribed[:, t])
+                parts.append(prog_t)
+                x = _run_stack(self.encoder, torch.cat(parts, dim=1))
+                for i, cell in enumerate(self.clstm):
+                    conv = cell.conv[1]
+                    gates = ops.conv3x3_cyl(x, conv.weight, conv.bias, 0, x1=hs[i])
+                    hs[i], cs[i] = ops.convlstm_gates(gates, cs[i])
+                    x = hs[i]
+                inc = _run_stack(self.decoder, x)
+                if t >= ctx:
+                    torch.add(prog_t, inc, out=out[:, t - ctx])
+                    prev = out[:, t - ctx]
+                else:
+                    prev = prog_t + inc
+            return out

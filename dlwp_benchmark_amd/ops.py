@@ -62,3 +62,74 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table:
                                             table.data_ptr(), out.data_ptr(), b, _lib.stream_ptr()),
                    "dlwp_window_attn_f32")
     return out
+
+
+ACTS = {"none": 0, "gelu": 1, "tanh": 2, "relu": 3, "silu": 4}
+
+
+def act_code(activation) -> int:
+    """Maps the reference's activation spec (module instance or the config string that the
+    reference `eval`s, e.g. "th.nn.GELU()", unet.py:292) to the kernel's activation id."""
+    n = activation if isinstance(activation, str) else type(activation).__name__
+    for key, tag in (("GELU", "gelu"), ("Tanh", "tanh"), ("LeakyReLU", None), ("ReLU", "relu"), ("SiLU", "silu"),
+                     ("Identity", "none")):
+        if key in n:
+            if tag is None:
+                break
+            return ACTS[tag]
+    raise _lib.DlwpError(f"activation {activation!r} has no fused kernel (supported: GELU, Tanh, ReLU, SiLU)")
+
+
+def conv3x3_cyl(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
+                x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CylinderPad(1) + Conv2d(3x3) + bias + activation on cat([x0, x1], 1) without the cat."""
+    _lib.require_cuda_tensor(x0, "x0")
+    _lib.require_cuda_tensor(x1, "x1")
+    _lib.require_cuda_tensor(weight, "weight")
+    x0 = x0.contiguous()
+    x1 = x1.contiguous() if x1 is not None else None
+    weight = weight.contiguous()
+    b, c0, h, w = x0.shape
+    c1 = x1.shape[1] if x1 is not None else 0
+    cout = weight.shape[0]
+    if tuple(weight.shape[1:]) != (c0 + c1, 3, 3):
+        raise _lib.DlwpError(f"weight {tuple(weight.shape)} does not match {c0}+{c1} input channels, 3x3")
+    y = torch.empty(b, cout, h, w, device=x0.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x0.device):
+        _lib.check(lib.dlwp_conv3x3_cyl_f32(x0.data_ptr(), c0, x1.data_ptr() if x1 is not None else None, c1,
+                                            weight.data_ptr(), bias.contiguous().data_ptr() if bias is not None else None,
+                                            y.data_ptr(), b, h, w, cout, act, _lib.stream_ptr()), "dlwp_conv3x3_cyl_f32")
+    return y
+
+
+def convlstm_gates(gates: torch.Tensor, c_prev: torch.Tensor):
+    _lib.require_cuda_tensor(gates, "gates")
+    _lib.require_cuda_tensor(c_prev, "c_prev")
+    gates, c_prev = gates.contiguous(), c_prev.contiguous()
+    b, c4, h, w = gates.shape
+    hid = c4 // 4
+    h_out, c_out = torch.empty_like(c_prev), torch.empty_like(c_prev)
+    lib = _lib.load()
+    with torch.cuda.device(gates.device):
+        _lib.check(lib.dlwp_convlstm_gates_f32(gates.data_ptr(), c_prev.data_ptr(), h_out.data_ptr(), c_out.data_ptr(),
+                                               b, hid, h, w, _lib.stream_ptr()), "dlwp_convlstm_gates_f32")
+    return h_out, c_out
+
+
+def afno2d_mix(xf: torch.Tensor, w1, b1, w2, b2, num_blocks: int, sparsity_threshold: float,
+               hard_thresholding_fraction: float) -> torch.Tensor:
+    """xf complex64 [B, H, Wf, C] (rfft2 output) -> mixed spectrum of the same shape."""
+    if not xf.is_cuda or xf.dtype != torch.complex64:
+        raise _lib.DlwpError("afno2d_mix needs a complex64 CUDA tensor")
+    xr = torch.view_as_real(xf.contiguous())
+    b, h, wf, c, _ = xr.shape
+    yr = torch.empty_like(xr)
+    lib = _lib.load()
+    with torch.cuda.device(xf.device):
+        _lib.check(lib.dlwp_afno2d_mix_f32(xr.data_ptr(), yr.data_ptr(), w1.contiguous().data_ptr(),
+                                           b1.contiguous().data_ptr(), w2.contiguous().data_ptr(),
+                                           b2.contiguous().data_ptr(), b, h, wf, c, num_blocks,
+                                           float(sparsity_threshold), float(hard_thresholding_fraction),
+                                           _lib.stream_ptr()), "dlwp_afno2d_mix_f32")
+    return torch.view_as_complex(yr)

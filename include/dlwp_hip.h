@@ -179,6 +179,35 @@ int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* desc, const float* qkv_dev,
                              const float* qkv_bias_dev, const float* table_dev, float* out_dev,
                              int32_t batch, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * AFNO2D frequency-domain mixing (reference models/fourcastnet/fourcastnet.py:87-121): complex
+ * block-diagonal 2-layer MLP with ReLU, mode truncation and softshrink over the rfft2 spectrum.
+ * xf_dev / yf_dev: interleaved complex64 [B, H, Wf, C, 2] (Wf = W/2+1); weights in the reference
+ * layouts w1,w2 [2, nb, bs, bs], b1,b2 [2, nb, bs] (device pointers).  yf is fully written
+ * (zeros outside the kept modes).
+ * ------------------------------------------------------------------------------------------ */
+int32_t dlwp_afno2d_mix_f32(const float* xf_dev, float* yf_dev, const float* w1_dev, const float* b1_dev,
+                            const float* w2_dev, const float* b2_dev, int32_t batch, int32_t height,
+                            int32_t wf, int32_t channels, int32_t num_blocks, float sparsity_threshold,
+                            float hard_thresholding_fraction, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CylinderPad(1) + Conv2d(3x3, padding 0) + bias + activation, input optionally given as two
+ * channel segments (folds the preceding torch.cat).  Reference: utils/utils.py:11-26;
+ * models/unet/unet.py:456-470, :512-525, :553; models/convlstm/convlstm.py:47-55, :94, :148-157.
+ * x0_dev [B, c0, H, W], x1_dev [B, c1, H, W] or NULL (c1 = 0), weight_dev [cout, c0+c1, 3, 3],
+ * bias_dev [cout] or NULL, y_dev [B, cout, H, W].  act: 0 none, 1 GELU(erf), 2 tanh, 3 ReLU, 4 SiLU.
+ * ------------------------------------------------------------------------------------------ */
+int32_t dlwp_conv3x3_cyl_f32(const float* x0_dev, int32_t c0, const float* x1_dev, int32_t c1,
+                             const float* weight_dev, const float* bias_dev, float* y_dev, int32_t batch,
+                             int32_t height, int32_t width, int32_t cout, int32_t act, void* stream);
+
+/* ConvLSTM cell gate math (models/convlstm/convlstm.py:96-109): gates_dev [B, 4*hidden, H, W] in the
+ * order (netin, igate, fgate, ogate), c_prev_dev [B, hidden, H, W] -> h_out_dev, c_out_dev. */
+int32_t dlwp_convlstm_gates_f32(const float* gates_dev, const float* c_prev_dev, float* h_out_dev,
+                                float* c_out_dev, int32_t batch, int32_t hidden, int32_t height,
+                                int32_t width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
