@@ -81,13 +81,13 @@ __device__ __forceinline__ void fwd_dft_accumulate(const float* s_tr, const floa
 // Y layout [B][H][KP][C] (c fastest): one 16-byte store per (ct, kt) per lane.
 template <int NT, int KP>
 __device__ __forceinline__ void store_y(float* __restrict__ ybuf, long long row, int nchan, int lane,
-                                        const f32x4 (&yacc)[NT][KP / 16]) {
+                                        const f32x4 (&yacc)[NT][KP / 16], int c0 = 0) {
   const int j = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
     for (int kt = 0; kt < KP / 16; ++kt)
-      *reinterpret_cast<f32x4*>(ybuf + (row * KP + kt * 16 + j) * nchan + 16 * ct + 4 * g) = yacc[ct][kt];
+      *reinterpret_cast<f32x4*>(ybuf + (row * KP + kt * 16 + j) * nchan + c0 + 16 * ct + 4 * g) = yacc[ct][kt];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,56 +419,57 @@ struct LayerParams {
   int B, H, W;
 };
 
-template <int KP, bool SKIP, bool ACT, bool EMIT_Y>
+// NO = 16-channel output tiles per wave: 2 -> one wave per row segment, 1 -> the row is split between
+// two waves (4 waves/SIMD at B*H = 2048 rows: on gfx950 VALU issue and latency hiding both improve
+// with occupancy, and the second wave's x loads hit L1/L2).
+template <int KP, bool SKIP, bool ACT, bool EMIT_Y, int NO>
 __global__ __launch_bounds__(256) void fno_layer_kernel(const LayerParams p) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  float* s_tr = smem + wave * (kC * kTrStride);
+  float* s_tr = smem + wave * (NO * 16 * kTrStride);
   const int HW = p.H * p.W;
   const int segs = p.W >> 6;
-  const int nrow = p.B * p.H;
+  constexpr int SPLIT = 2 / NO;
+  const int nunit = p.B * p.H * SPLIT;
 
-  float wa[8][2];
-  if (SKIP) {
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      wa[s][0] = p.wsp[(s * 2 + 0) * 64 + lane];
-      wa[s][1] = p.wsp[(s * 2 + 1) * 64 + lane];
-    }
-  }
-  f32x4 bias4[2];
-  bias4[0] = *reinterpret_cast<const f32x4*>(p.bias + 4 * g);
-  bias4[1] = *reinterpret_cast<const f32x4*>(p.bias + 16 + 4 * g);
-
-  for (int row = blockIdx.x * nw + wave; row < nrow; row += gridDim.x * nw) {
+  for (int unit = blockIdx.x * nw + wave; unit < nunit; unit += gridDim.x * nw) {
+    const int row = unit / SPLIT, ot0 = (unit % SPLIT) * NO;   // first 16-channel output tile of this wave
     const int h = row % p.H, b = row / p.H;
-    // Z operands of this row: A[i = o][k = k'] -> lane reads Z[k' = 4 s + g][o = j (+16)]
-    float z[KP / 4][2];
+    float wa[8][NO];
+    if (SKIP) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int ot = 0; ot < NO; ++ot) wa[s][ot] = p.wsp[(s * 2 + ot0 + ot) * 64 + lane];
+    }
+    f32x4 bias4[NO];
+#pragma unroll
+    for (int ot = 0; ot < NO; ++ot) bias4[ot] = *reinterpret_cast<const f32x4*>(p.bias + 16 * (ot0 + ot) + 4 * g);
+    // Z operands of this row: A[i = o][k = k'] -> lane reads Z[k' = 4 s + g][o = 16 ot + j]
+    float z[KP / 4][NO];
     {
       const float* zr = p.zbuf + (long long)row * KP * kC;
 #pragma unroll
-      for (int s = 0; s < KP / 4; ++s) {
-        z[s][0] = zr[(4 * s + g) * kC + j];
-        z[s][1] = zr[(4 * s + g) * kC + 16 + j];
-      }
+      for (int s = 0; s < KP / 4; ++s)
+#pragma unroll
+        for (int ot = 0; ot < NO; ++ot) z[s][ot] = zr[(4 * s + g) * kC + 16 * (ot0 + ot) + j];
     }
-    f32x4 yacc[2][KP / 16];
+    f32x4 yacc[NO][KP / 16];
     if (EMIT_Y) {
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot)
+      for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
         for (int kt = 0; kt < KP / 16; ++kt) yacc[ot][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int ws = 0; ws < segs; ++ws) {
       const int w0 = ws * 64;
       const long long pix = (long long)h * p.W + w0 + 4 * j;
-      f32x4 acc[2][4];
+      f32x4 acc[NO][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[0][q] = bias4[0];
-        acc[1][q] = bias4[1];
-      }
+      for (int ot = 0; ot < NO; ++ot)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[ot][q] = bias4[ot];
       if (SKIP) {
         f32x4 xs[8];
 #pragma unroll
@@ -477,47 +478,45 @@ __global__ __launch_bounds__(256) void fno_layer_kernel(const LayerParams p) {
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            acc[0][q] = mfma16x16x4(wa[s][0], xs[s][q], acc[0][q]);
-            acc[1][q] = mfma16x16x4(wa[s][1], xs[s][q], acc[1][q]);
-          }
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ot = 0; ot < NO; ++ot) acc[ot][q] = mfma16x16x4(wa[s][ot], xs[s][q], acc[ot][q]);
       }
 #pragma unroll
       for (int s = 0; s < KP / 4; ++s) {
         const f32x4 tw = *reinterpret_cast<const f32x4*>(p.t + (long long)(4 * s + g) * p.W + w0 + 4 * j);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[0][q] = mfma16x16x4(z[s][0], tw[q], acc[0][q]);
-          acc[1][q] = mfma16x16x4(z[s][1], tw[q], acc[1][q]);
-        }
-      }
-      f32x4 vv[2][4];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot)
+          for (int ot = 0; ot < NO; ++ot) acc[ot][q] = mfma16x16x4(z[s][ot], tw[q], acc[ot][q]);
+      }
+      f32x4 vv[NO][4];
+#pragma unroll
+      for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
         for (int r = 0; r < 4; ++r) vv[ot][r] = f32x4{acc[ot][0][r], acc[ot][1][r], acc[ot][2][r], acc[ot][3][r]};
       if (ACT) {
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
+        for (int ot = 0; ot < NO; ++ot) {
           gelu_erf8(vv[ot][0], vv[ot][1]);
           gelu_erf8(vv[ot][2], vv[ot][3]);
         }
       }
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot)
+      for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = 16 * ot + 4 * g + r;
-          *reinterpret_cast<f32x4*>(p.y + ((long long)b * kC + co) * HW + pix) = vv[ot][r];
-          if (EMIT_Y) *reinterpret_cast<f32x4*>(s_tr + co * kTrStride + 4 * j) = vv[ot][r];
+          const int cl = 16 * ot + 4 * g + r;
+          *reinterpret_cast<f32x4*>(p.y + ((long long)b * kC + 16 * ot0 + cl) * HW + pix) = vv[ot][r];
+          if (EMIT_Y) *reinterpret_cast<f32x4*>(s_tr + cl * kTrStride + 4 * j) = vv[ot][r];
         }
       if (EMIT_Y) {
         wave_lds_fence();
-        fwd_dft_accumulate<2, KP>(s_tr, p.tt, w0, lane, yacc);
+        fwd_dft_accumulate<NO, KP>(s_tr, p.tt, w0, lane, yacc);
         wave_lds_fence();
       }
     }
-    if (EMIT_Y) store_y<2, KP>(p.ybuf, row, kC, lane, yacc);
+    if (EMIT_Y) store_y<NO, KP>(p.ybuf, row, kC, lane, yacc, 16 * ot0);
   }
 }
 
@@ -814,13 +813,21 @@ static int32_t launch_modes(const SpectralCore& sc, const float* ybuf, float* zb
 
 template <bool SKIP, bool ACT, bool EMIT_Y>
 static int32_t launch_layer(const SpectralCore& sc, const LayerParams& lp, hipStream_t s) {
-  const size_t lds = EMIT_Y ? (size_t)4 * kC * kTrStride * sizeof(float) : 0;
-  const int grid = grid_rows(lp.B * lp.H, 4);
+  // NO = 1 (row split between two waves, 4 waves/SIMD at the headline size) measured SLOWER than one
+  // wave per row (16.6 vs 13.7 us event-timed: the duplicated x / Z / weight loads cost more than the
+  // occupancy buys), so it stays off; kept as a template parameter for larger grids.
+  const int nrow = lp.B * lp.H;
+  const bool split = false;
+  const size_t lds = EMIT_Y ? (size_t)4 * (split ? 16 : 32) * kTrStride * sizeof(float) : 0;
+  const int grid = grid_rows(nrow * (split ? 2 : 1), 4);
+#define DLWP_LAUNCH_LAYER(KP_, NO_) \
+  hipLaunchKernelGGL((fno_layer_kernel<KP_, SKIP, ACT, EMIT_Y, NO_>), dim3(grid), dim3(256), lds, s, lp)
   if (sc.KP == 16) {
-    hipLaunchKernelGGL((fno_layer_kernel<16, SKIP, ACT, EMIT_Y>), dim3(grid), dim3(256), lds, s, lp);
+    if (split) DLWP_LAUNCH_LAYER(16, 1); else DLWP_LAUNCH_LAYER(16, 2);
   } else {
-    hipLaunchKernelGGL((fno_layer_kernel<32, SKIP, ACT, EMIT_Y>), dim3(grid), dim3(256), lds, s, lp);
+    if (split) DLWP_LAUNCH_LAYER(32, 1); else DLWP_LAUNCH_LAYER(32, 2);
   }
+#undef DLWP_LAUNCH_LAYER
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
