@@ -7,8 +7,10 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dlwp_hip.h"
@@ -205,5 +207,70 @@ __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
   v = f32x4{r4, r5, r6, r7};
 }
 #undef DLWP_A4
+
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix pipe ("bf16x6")
+//   x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (exact to 2^-24 |x|)
+//   a*b ~= al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh   (dropped terms <= 2^-24 |a b|)
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Measured (tools) as accurate as a plain fp32 GEMM
+// (rel. error 1.1e-7 vs 2.9e-7 at K = 256).  Why: on gfx950 the fp32 MFMA runs on the fp32 VALU lanes
+// and cannot overlap VALU work (tools/ubench_fp32.hip), while the bf16 matrix pipe is separate and 16x
+// faster per flop -- six bf16 MFMAs cost 6/16 of one fp32 MFMA's time AND leave the fp32 lanes to GELU.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[i = l&15][k = 8*(l>>4) + 0..7] and
+// B[k = 8*(l>>4) + 0..7][j = l&15] (8 bf16 = 4 dwords, element 0 in the low half of dword 0);
+// D register r of lane l is D[row = 4*(l>>4) + r][col = l&15].
+__device__ __forceinline__ f32x4 mfma16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // RNE, a in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2v));
+}
+
+// three-way bf16 split of a pair of floats: 9 VALU issue slots (3 cvt_pk, 4 unpack, 2 packed subtract)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16(s0, s1);
+}
+
+// D += A*B with A = (ah, am, al), B = (bh, bm, bl), smallest terms first
+__device__ __forceinline__ f32x4 mfma_bf16x6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+  c = mfma16x16x32_bf16(a[2], b[0], c);
+  c = mfma16x16x32_bf16(a[0], b[2], c);
+  c = mfma16x16x32_bf16(a[1], b[1], c);
+  c = mfma16x16x32_bf16(a[1], b[0], c);
+  c = mfma16x16x32_bf16(a[0], b[1], c);
+  c = mfma16x16x32_bf16(a[0], b[0], c);
+  return c;
+}
+
+// host: round-to-nearest-even bf16 split of one float (matches v_cvt_pk_bf16_f32 for finite values)
+inline void split3_host(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  auto to_bf16 = [](float v) -> uint16_t {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto from_bf16 = [](uint16_t b) -> float {
+    uint32_t u = (uint32_t)b << 16;
+    float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+  };
+  h = to_bf16(x);
+  const float r = x - from_bf16(h);
+  m = to_bf16(r);
+  const float s2 = r - from_bf16(m);
+  l = to_bf16(s2);
+}
 
 }  // namespace dlwp

@@ -272,6 +272,166 @@ __global__ __launch_bounds__(256) void pw_mlp2_kernel(const MlpParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// lifting, bf16x6 variant: out[32] = W2 * gelu(W1 * x + b1) + b2, plus the W-direction DFT of out.
+// Layer 1 (Cin <= 32 -> hid) stays on fp32 MFMA (K is tiny); layer 2 (hid -> 32, K = hid) runs on the
+// bf16 matrix pipe.  Hidden tiles are processed in PAIRS: the GELU outputs of tiles (2u, 2u+1) are
+// exactly the 8 k-slots a lane supplies to one v_mfma_f32_16x16x32_bf16 -- k-slot (g, jj) = hidden
+// channel 16*(2u + jj/4) + 4g + jj%4, i.e. the accumulator registers as they stand (no lane movement).
+//   p.w2p here is W2 split and packed as [hid/32][3 parts][2 out tiles][64 lanes][4 dwords].
+// ---------------------------------------------------------------------------------------------
+template <int CIN_STEPS, int KP>
+__global__ __launch_bounds__(512) void pw_lift_bf16x6_kernel(const MlpParams p) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int ntile = p.hid >> 4, npair = ntile >> 1;
+  u32x4* s_w2 = reinterpret_cast<u32x4*>(smem);                      // [npair][3][2][64]
+  float* s_w1 = reinterpret_cast<float*>(s_w2 + npair * 6 * 64);     // [ntile][CIN_STEPS][64]
+  float* s_b1 = s_w1 + ntile * CIN_STEPS * 64;                       // [hid]
+  float* s_tr = s_b1 + p.hid + wave * (kC * kTrStride);
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.w2p);
+    for (int i = tid; i < npair * 6 * 64; i += blockDim.x) s_w2[i] = src[i];
+    for (int i = tid; i < ntile * CIN_STEPS * 64; i += blockDim.x) s_w1[i] = p.w1p[i];
+    for (int i = tid; i < p.hid; i += blockDim.x) s_b1[i] = p.b1[i];
+  }
+  __syncthreads();
+  const int HW = p.H * p.W, segs = p.W >> 6, nrow = p.B * p.H;
+  f32x4 bias2[2];
+  bias2[0] = *reinterpret_cast<const f32x4*>(p.b2 + 4 * g);
+  bias2[1] = *reinterpret_cast<const f32x4*>(p.b2 + 16 + 4 * g);
+
+  for (int row = blockIdx.x * nw + wave; row < nrow; row += gridDim.x * nw) {
+    const int h = row % p.H, b = row / p.H;
+    f32x4 yacc[2][KP / 16];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int kt = 0; kt < KP / 16; ++kt) yacc[ot][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ws = 0; ws < segs; ++ws) {
+      const int w0 = ws * 64;
+      const long long pix = (long long)h * p.W + w0 + 4 * j;
+      f32x4 xs[CIN_STEPS];
+#pragma unroll
+      for (int s = 0; s < CIN_STEPS; ++s) {
+        const float* cp = chan_ptr(p.x, 4 * s + g, b, HW);
+        xs[s] = cp ? *reinterpret_cast<const f32x4*>(cp + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      f32x4 acc2[2][4];
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc2[ot][q] = bias2[ot];
+
+      // Software pipeline over units (tile pair u, pixel-chain pair qp): while the fp32 lanes do layer 1,
+      // GELU and the 3-way bf16 split of unit n (-> B operands bg), the bf16 matrix pipe does layer 2 of
+      // unit n-1.  Three slots per trip, 8 bf16 MFMAs each, fenced so hipcc keeps the interleave (an
+      // in-order wave that issues its MFMAs back to back cannot issue VALU work meanwhile).
+      // (every index into bg / acc2 / xs below is a compile-time constant: runtime-indexed register
+      // arrays go to scratch)
+      u32x4 bg0[2][3], bg1[2][3];   // ping-pong B operands: [q in pair][part]
+      f32x4 a1[2][2];               // [tile in pair][q in pair]
+      u32x4 wa[2][3];               // layer-2 A operands of the unit in flight on the matrix pipe
+      const int nunit = npair * 2;  // unit n = (tile pair n >> 1, chain pair n & 1)
+      auto unit_valu_fc1 = [&](int u, auto qpc) {
+        constexpr int qp = decltype(qpc)::value;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * u + tt;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) a1[tt][qq] = bb;
+#pragma unroll
+          for (int s = 0; s < CIN_STEPS; ++s) {
+            const float a = s_w1[(t * CIN_STEPS + s) * 64 + lane];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) a1[tt][qq] = mfma16x16x4(a, xs[s][2 * qp + qq], a1[tt][qq]);
+          }
+        }
+      };
+      auto unit_split = [&](u32x4(&bg)[2][3]) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {   // dword i: k-slots 2i, 2i+1 -> tile i/2, registers 2(i%2), 2(i%2)+1
+            unsigned hh, mm, ll;
+            split3_pair(a1[i / 2][qq][2 * (i % 2)], a1[i / 2][qq][2 * (i % 2) + 1], hh, mm, ll);
+            bg[qq][0][i] = hh;
+            bg[qq][1][i] = mm;
+            bg[qq][2][i] = ll;
+          }
+      };
+      auto load_wa = [&](int u) {
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) wa[ot][pp] = s_w2[((u * 3 + pp) * 2 + ot) * 64 + lane];
+      };
+      // 8 of the 24 bf16 MFMAs of a unit: terms {2 slot, 2 slot + 1} of every (ot, q) accumulator,
+      // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+      auto unit_mfma = [&](const u32x4(&bg)[2][3], auto qpc, auto slotc) {
+        constexpr int qp = decltype(qpc)::value, slot = decltype(slotc)::value;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int term = 2 * slot; term < 2 * slot + 2; ++term)
+#pragma unroll
+          for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+              acc2[ot][2 * qp + qq] = mfma16x16x32_bf16(wa[ot][PA[term]], bg[qq][PB[term]], acc2[ot][2 * qp + qq]);
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      // one trip: matrix pipe = layer 2 of the previous unit (chain pair QM, operands bgm),
+      //           fp32 lanes  = layer 1 + GELU + split of this unit (chain pair QV -> bgv)
+      auto trip = [&](int u_m, int u_v, const u32x4(&bgm)[2][3], u32x4(&bgv)[2][3], auto qm, auto qv) {
+        load_wa(u_m);
+        unit_valu_fc1(u_v, qv);
+        unit_mfma(bgm, qm, I0{});
+        gelu_erf8(a1[0][0], a1[0][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        unit_mfma(bgm, qm, I1{});
+        gelu_erf8(a1[1][0], a1[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        unit_mfma(bgm, qm, I2{});
+        unit_split(bgv);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // prologue: unit 0 (tile pair 0, chains 0-1) on the fp32 lanes only
+      unit_valu_fc1(0, I0{});
+      gelu_erf8(a1[0][0], a1[0][1]);
+      gelu_erf8(a1[1][0], a1[1][1]);
+      unit_split(bg0);
+      for (int u = 0; u < npair; ++u) {
+        trip(u, u, bg0, bg1, I0{}, I1{});                            // MFMA unit (u,0) | VALU unit (u,1)
+        if (u + 1 < npair) trip(u, u + 1, bg1, bg0, I1{}, I0{});      // MFMA unit (u,1) | VALU unit (u+1,0)
+      }
+      load_wa(npair - 1);
+      unit_mfma(bg1, I1{}, I0{});
+      unit_mfma(bg1, I1{}, I1{});
+      unit_mfma(bg1, I1{}, I2{});
+      (void)nunit;
+
+      // epilogue: acc2[ot][q][r] = out[co = 16 ot + 4 g + r][pixel 4 j + q]
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * ot + 4 * g + r;
+          const f32x4 v = {acc2[ot][0][r], acc2[ot][1][r], acc2[ot][2][r], acc2[ot][3][r]};
+          *reinterpret_cast<f32x4*>(p.out + (long long)b * p.out_bstride + (long long)co * HW + pix) = v;
+          *reinterpret_cast<f32x4*>(s_tr + co * kTrStride + 4 * j) = v;
+        }
+      wave_lds_fence();
+      fwd_dft_accumulate<2, KP>(s_tr, p.tt, w0, lane, yacc);
+      wave_lds_fence();
+    }
+    store_y<2, KP>(p.ybuf, row, kC, lane, yacc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // projection with few outputs (CO <= 4):  out = W2 * gelu(W1 * h + b1) + b2 (+ residual)
 // Layer 1 (32 -> hid) stays on fp32 MFMA; layer 2 (hid -> CO) would waste 12+ of 16 MFMA rows, and
 // fp32 MFMA shares the fp32 lanes with the VALU on gfx950 (tools/ubench_fp32.hip: the two do not
@@ -401,6 +561,139 @@ __global__ __launch_bounds__(256) void pw_proj_small_kernel(const MlpParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// projection, bf16x6 variant: layer 1 (32 -> hid) runs on the bf16 matrix pipe as six
+// v_mfma_f32_16x16x32_bf16 per (hidden tile, pixel chain) -- K = 32 input channels is exactly one
+// instruction deep -- so the fp32 lanes only do GELU and the CO*16 FMAs of layer 2.
+//   lane (j = l&15, g = l>>4) loads channels 8g..8g+7 (the 8 k-slots it supplies) of pixels 4j..4j+3;
+//   p.w1p here is W1 split and packed as [hid/16][3 parts][64 lanes][4 dwords].
+// ---------------------------------------------------------------------------------------------
+template <int CO, bool RESID>
+__global__ __launch_bounds__(512) void pw_proj_bf16x6_kernel(const MlpParams p) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int ntile = p.hid >> 4;
+  u32x4* s_w1 = reinterpret_cast<u32x4*>(smem);                   // [ntile][3][64]
+  float* s_b1 = reinterpret_cast<float*>(s_w1 + ntile * 3 * 64);  // [hid]
+  float* s_w2 = s_b1 + p.hid;                                     // [ntile][CO][16]
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.w1p);
+    for (int i = tid; i < ntile * 3 * 64; i += blockDim.x) s_w1[i] = src[i];
+    for (int i = tid; i < p.hid; i += blockDim.x) s_b1[i] = p.b1[i];
+    for (int i = tid; i < ntile * CO * 16; i += blockDim.x) s_w2[i] = p.w2p[i];
+  }
+  __syncthreads();
+  const int HW = p.H * p.W, segs = p.W >> 6, nrow = p.B * p.H;
+  for (int row = blockIdx.x * nw + wave; row < nrow; row += gridDim.x * nw) {
+    const int h = row % p.H, b = row / p.H;
+    for (int ws = 0; ws < segs; ++ws) {
+      const int w0 = ws * 64;
+      const long long pix = (long long)h * p.W + w0 + 4 * j;
+      u32x4 bx[4][3];  // B operands per pixel chain q: (h, m, l) parts of channels 8g..8g+7
+      {
+        f32x4 xs[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          xs[c] = *reinterpret_cast<const f32x4*>(p.x.seg[0].ptr + (long long)b * p.x.seg[0].bstride +
+                                                  (long long)(8 * g + c) * HW + pix);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned hh, mm, ll;
+            split3_pair(xs[2 * i][q], xs[2 * i + 1][q], hh, mm, ll);
+            bx[q][0][i] = hh;
+            bx[q][1][i] = mm;
+            bx[q][2][i] = ll;
+          }
+      }
+      float po[CO][4];
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) po[co][q] = 0.f;
+      auto fc1 = [&](int t, f32x4(&a1)[4]) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
+        u32x4 wa[3];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) wa[pp] = s_w1[(t * 3 + pp) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a1[q] = mfma_bf16x6(wa, bx[q], bb);
+      };
+      f32x4 a_cur[4], a_nxt[4], g_prev[4], g_new[4];
+      fc1(0, a_cur);
+      fc1(ntile > 1 ? 1 : 0, a_nxt);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g_prev[q] = a_cur[q];
+      gelu_erf8(g_prev[0], g_prev[1]);
+      gelu_erf8(g_prev[2], g_prev[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+      for (int t = 1; t < ntile; ++t) {
+        const int tn = (t + 1 < ntile) ? t + 1 : t;
+        u32x4 wa[3];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) wa[pp] = s_w1[(tn * 3 + pp) * 64 + lane];
+        f32x4 w2v[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+          w2v[co] = *reinterpret_cast<const f32x4*>(s_w2 + ((t - 1) * CO + co) * 16 + 4 * g);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * tn + 4 * g);
+        // two slots: the bf16 MFMAs of tile tn for two pixel chains (matrix pipe), then GELU of two
+        // accumulator fragments of tile t and the layer-2 FMAs of tile t-1 (fp32 lanes)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a_nxt[2 * i] = mfma_bf16x6(wa, bx[2 * i], bb);
+          a_nxt[2 * i + 1] = mfma_bf16x6(wa, bx[2 * i + 1], bb);
+          g_new[2 * i] = a_cur[2 * i];
+          g_new[2 * i + 1] = a_cur[2 * i + 1];
+          gelu_erf8(g_new[2 * i], g_new[2 * i + 1]);
+#pragma unroll
+          for (int co = 0; co < CO; ++co)
+#pragma unroll
+            for (int qq = 2 * i; qq < 2 * i + 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) po[co][qq] = fmaf(w2v[co][r], g_prev[qq][r], po[co][qq]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          g_prev[q] = g_new[q];
+          a_cur[q] = a_nxt[q];
+        }
+      }
+      {
+        const int t = ntile - 1;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_w2 + (t * CO + co) * 16 + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) po[co][q] = fmaf(w2[r], g_prev[q][r], po[co][q]);
+        }
+      }
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = po[co][q];
+          x += __shfl_xor(x, 16);
+          x += __shfl_xor(x, 32);
+          if (g == co) v[q] = x;
+        }
+      if (g < CO && g < p.cout) {
+        const float bias = p.b2[g];
+        v += f32x4{bias, bias, bias, bias};
+        if (RESID) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)b * p.resid_bstride + (long long)g * HW + pix);
+        *reinterpret_cast<f32x4*>(p.out + (long long)b * p.out_bstride + (long long)g * HW + pix) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // spectral layer:  y = act( skip(x) + bias + inverse-W-DFT(Z) ),  optionally Y_next = fwd-W-DFT(y)
 //   skip  : neuralop FNOBlocks.fno_skips[l] (1x1 conv, no bias)
 //   bias  : SpectralConv.bias[l]
@@ -417,17 +710,25 @@ struct LayerParams {
   const float* tt;    // TT[W][KP]
   float* ybuf;        // [B][H][32][KP]
   int B, H, W;
+  int stagger;        // delay of waves 4-7 in units of s_sleep(32) = 2048 cycles
 };
 
 // NO = 16-channel output tiles per wave: 2 -> one wave per row segment, 1 -> the row is split between
 // two waves (4 waves/SIMD at B*H = 2048 rows: on gfx950 VALU issue and latency hiding both improve
 // with occupancy, and the second wave's x loads hit L1/L2).
 template <int KP, bool SKIP, bool ACT, bool EMIT_Y, int NO>
-__global__ __launch_bounds__(256) void fno_layer_kernel(const LayerParams p) {
+__global__ __launch_bounds__(512) void fno_layer_kernel(const LayerParams p) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   float* s_tr = smem + wave * (NO * 16 * kTrStride);
+  // Stagger: an 8-wave workgroup puts waves w and w+4 on the same SIMD.  Every wave runs
+  // load -> MFMA -> store once; started together all waves hit memory, then the fp32 pipe, then memory
+  // again (PMC: ~45 % of wave life in s_waitcnt).  Delaying the second half by about one load phase
+  // lets its loads overlap the first half's MFMAs and its MFMAs the first half's stores.
+  if (p.stagger > 0 && __builtin_amdgcn_readfirstlane(wave) >= 4) {
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   const int HW = p.H * p.W;
   const int segs = p.W >> 6;
   constexpr int SPLIT = 2 / NO;
@@ -818,10 +1119,16 @@ static int32_t launch_layer(const SpectralCore& sc, const LayerParams& lp, hipSt
   // occupancy buys), so it stays off; kept as a template parameter for larger grids.
   const int nrow = lp.B * lp.H;
   const bool split = false;
-  const size_t lds = EMIT_Y ? (size_t)4 * (split ? 16 : 32) * kTrStride * sizeof(float) : 0;
-  const int grid = grid_rows(nrow * (split ? 2 : 1), 4);
+  const size_t lds = EMIT_Y ? (size_t)8 * (split ? 16 : 32) * kTrStride * sizeof(float) : 0;
+  const int grid = grid_rows(nrow * (split ? 2 : 1), 8);
+  if (lds > 48 * 1024) {
+    DLWP_HIP_CHECK(allow_lds(fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 2>, lds));
+    DLWP_HIP_CHECK(allow_lds(fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 2>, lds));
+    DLWP_HIP_CHECK(allow_lds(fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 1>, lds));
+    DLWP_HIP_CHECK(allow_lds(fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 1>, lds));
+  }
 #define DLWP_LAUNCH_LAYER(KP_, NO_) \
-  hipLaunchKernelGGL((fno_layer_kernel<KP_, SKIP, ACT, EMIT_Y, NO_>), dim3(grid), dim3(256), lds, s, lp)
+  hipLaunchKernelGGL((fno_layer_kernel<KP_, SKIP, ACT, EMIT_Y, NO_>), dim3(grid), dim3(512), lds, s, lp)
   if (sc.KP == 16) {
     if (split) DLWP_LAUNCH_LAYER(16, 1); else DLWP_LAUNCH_LAYER(16, 2);
   } else {
@@ -845,8 +1152,8 @@ struct dlwp_fno2d_plan {
   int cin = 0, hid_l = 0, hid_p = 0, cout = 0, L = 0, H = 0, W = 0;
   int cin_steps = 0;
   SpectralCore sc;
-  DevBuf lift_w1p, lift_b1, lift_w2p, lift_b2;
-  DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v;
+  DevBuf lift_w1p, lift_b1, lift_w2p, lift_b2, lift_w2b;
+  DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v, proj_w1b;
   int proj_co = 0;  // outputs handled by pw_proj_small_kernel (1, 2 or 4), 0 = generic MFMA path
   std::vector<DevBuf> wt, wsp, sbias;
 };
@@ -860,6 +1167,43 @@ static void pack_w1(std::vector<float>& dst, const float* w1, int hid, int cin, 
         if (ci < cin) dst[((size_t)t * cin_steps + s) * 64 + l] = w1[(size_t)ch * cin + ci];
       }
 }
+// bf16x6 A operands of a [rows][K = 32] matrix block: [rows/16][3 parts][64 lanes][4 dwords]
+static void pack_a_bf16x3(std::vector<uint32_t>& dst, const float* w, int rows, int ld) {
+  dst.assign((size_t)(rows / 16) * 3 * 64 * 4, 0u);
+  for (int t = 0; t < rows / 16; ++t)
+    for (int l = 0; l < 64; ++l)
+      for (int d = 0; d < 4; ++d) {
+        uint16_t h[2], m[2], lo[2];
+        for (int e = 0; e < 2; ++e) split3_host(w[(size_t)(16 * t + (l & 15)) * ld + 8 * (l >> 4) + 2 * d + e], h[e], m[e], lo[e]);
+        const size_t base = ((size_t)t * 3 * 64 + l) * 4 + d;
+        dst[base + 0 * 64 * 4] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+        dst[base + 1 * 64 * 4] = (uint32_t)m[0] | ((uint32_t)m[1] << 16);
+        dst[base + 2 * 64 * 4] = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+      }
+}
+
+// bf16x6 A operands of layer 2 of the lifting MLP: W2 [32][hid] -> [hid/32][3 parts][2 out tiles][64 lanes][4 dwords];
+// k-slot (g, jj) of tile pair u is hidden channel 16*(2u + jj/4) + 4g + jj%4 (accumulator order of layer 1)
+static void pack_lift_w2_bf16x3(std::vector<uint32_t>& dst, const float* w2, int hid) {
+  const int npair = hid / 32;
+  dst.assign((size_t)npair * 3 * 2 * 64 * 4, 0u);
+  for (int u = 0; u < npair; ++u)
+    for (int ot = 0; ot < 2; ++ot)
+      for (int l = 0; l < 64; ++l)
+        for (int d = 0; d < 4; ++d) {
+          uint16_t h[2], m[2], lo[2];
+          for (int e = 0; e < 2; ++e) {
+            const int jj = 2 * d + e, g = l >> 4;
+            const int ch = 16 * (2 * u + jj / 4) + 4 * g + jj % 4;
+            split3_host(w2[(size_t)(16 * ot + (l & 15)) * hid + ch], h[e], m[e], lo[e]);
+          }
+          auto at = [&](int part) -> uint32_t& { return dst[((((size_t)u * 3 + part) * 2 + ot) * 64 + l) * 4 + d]; };
+          at(0) = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+          at(1) = (uint32_t)m[0] | ((uint32_t)m[1] << 16);
+          at(2) = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+        }
+}
+
 static void pack_w2(std::vector<float>& dst, const float* w2, int hid, int cout, int cout_tiles) {
   dst.assign((size_t)(hid / 16) * 4 * cout_tiles * 64, 0.f);
   for (int t = 0; t < hid / 16; ++t)
@@ -909,6 +1253,12 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
     if ((e = up(p->lift_w2p, tmp)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
     if ((e = p->lift_b2.upload(d->lift_b2, (size_t)kC * 4, s)) != hipSuccess) break;
+    if (p->hid_l % 32 == 0) {
+      std::vector<uint32_t> wb;
+      pack_lift_w2_bf16x3(wb, d->lift_w2, p->hid_l);
+      if ((e = p->lift_w2b.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
+      if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+    }
     pack_w1(tmp, d->proj_w1, p->hid_p, kC, 8);
     if ((e = up(p->proj_w1p, tmp)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
@@ -923,6 +1273,10 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
         for (int co = 0; co < p->cout; ++co)
           for (int k = 0; k < 16; ++k) wv[((size_t)t * p->proj_co + co) * 16 + k] = d->proj_w2[(size_t)co * p->hid_p + 16 * t + k];
       if ((e = up(p->proj_w2v, wv)) != hipSuccess) break;
+      if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+      std::vector<uint32_t> wb;
+      pack_a_bf16x3(wb, d->proj_w1, p->hid_p, kC);
+      if ((e = p->proj_w1b.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
       if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
     }
     std::vector<float> b2(16, 0.f);
@@ -958,6 +1312,26 @@ extern "C" int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan) {
 }
 
 namespace {
+// delay of the second half of each layer-kernel workgroup (units of 2048 cycles); tunable for experiments
+int layer_stagger() {
+  static const int v = [] {
+    const char* e = getenv("DLWP_LAYER_STAGGER");
+    return e ? atoi(e) : 0;  // measured: every delay > 0 is slower (per-wave latency chain, not contention)
+  }();
+  return v;
+}
+
+// fp32 GEMMs on the bf16 matrix pipe (common.hpp "bf16x6"); DLWP_FP32_MFMA=1 selects the fp32-MFMA
+// kernels instead (kept for A/B measurements and as the numerical cross-check in the tests)
+int g_fp32_mfma = -1;  // -1: read DLWP_FP32_MFMA once, 0: bf16x6, 1: fp32 MFMA
+bool use_bf16x6() {
+  if (g_fp32_mfma < 0) {
+    const char* e = getenv("DLWP_FP32_MFMA");
+    g_fp32_mfma = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return g_fp32_mfma == 0;
+}
+
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
 struct KernelTimer {
   enum { LIFT = 0, MODES = 1, LAYER = 2, PROJ = 3, NCLASS = 4 };
@@ -994,8 +1368,16 @@ FnoWorkspace carve(const dlwp_fno2d_plan* p, int B, void* base) {
 }
 
 template <int CS>
-int32_t launch_lift_cs(const MlpParams& mp, int kp, int grid, size_t lds, hipStream_t s) {
-  if (kp == 16) {
+int32_t launch_lift_cs(const MlpParams& mp, int kp, int grid, size_t lds, hipStream_t s, bool bf, size_t lds_bf) {
+  if (bf) {
+    if (kp == 16) {
+      DLWP_HIP_CHECK(allow_lds(pw_lift_bf16x6_kernel<CS, 16>, lds_bf));
+      hipLaunchKernelGGL((pw_lift_bf16x6_kernel<CS, 16>), dim3((grid + 1) / 2), dim3(512), lds_bf, s, mp);
+    } else {
+      DLWP_HIP_CHECK(allow_lds(pw_lift_bf16x6_kernel<CS, 32>, lds_bf));
+      hipLaunchKernelGGL((pw_lift_bf16x6_kernel<CS, 32>), dim3((grid + 1) / 2), dim3(512), lds_bf, s, mp);
+    }
+  } else if (kp == 16) {
     DLWP_HIP_CHECK(allow_lds(pw_mlp2_kernel<CS, 2, 16, true, false>, lds));
     hipLaunchKernelGGL((pw_mlp2_kernel<CS, 2, 16, true, false>), dim3(grid), dim3(256), lds, s, mp);
   } else {
@@ -1023,18 +1405,23 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     mp.B = B; mp.H = p->H; mp.W = p->W;
     const int nt = p->hid_l / 16;
     const size_t lds = ((size_t)nt * p->cin_steps * 64 + p->hid_l + (size_t)nt * 4 * 2 * 64 + 4 * kC * kTrStride) * 4;
+    const bool bf = use_bf16x6() && p->lift_w2b.p != nullptr;
+    // 8-wave workgroups: the ~53 KB of staged weights are shared by 8 rows and one workgroup per CU
+    // keeps 2 waves per SIMD resident (4-wave workgroups at 88 KB of LDS ran one per CU, in two rounds)
+    const size_t lds_bf = ((size_t)(nt / 2) * 6 * 64 * 4 + (size_t)nt * p->cin_steps * 64 + p->hid_l + 8 * kC * kTrStride) * 4;
+    if (bf) mp.w2p = p->lift_w2b.as<float>();
     const int grid = grid_rows(nrow, 4);
     int32_t rc;
     if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::LIFT));
     switch (p->cin_steps) {
-      case 1: rc = launch_lift_cs<1>(mp, p->sc.KP, grid, lds, s); break;
-      case 2: rc = launch_lift_cs<2>(mp, p->sc.KP, grid, lds, s); break;
-      case 3: rc = launch_lift_cs<3>(mp, p->sc.KP, grid, lds, s); break;
-      case 4: rc = launch_lift_cs<4>(mp, p->sc.KP, grid, lds, s); break;
-      case 5: rc = launch_lift_cs<5>(mp, p->sc.KP, grid, lds, s); break;
-      case 6: rc = launch_lift_cs<6>(mp, p->sc.KP, grid, lds, s); break;
-      case 7: rc = launch_lift_cs<7>(mp, p->sc.KP, grid, lds, s); break;
-      default: rc = launch_lift_cs<8>(mp, p->sc.KP, grid, lds, s); break;
+      case 1: rc = launch_lift_cs<1>(mp, p->sc.KP, grid, lds, s, bf, lds_bf); break;
+      case 2: rc = launch_lift_cs<2>(mp, p->sc.KP, grid, lds, s, bf, lds_bf); break;
+      case 3: rc = launch_lift_cs<3>(mp, p->sc.KP, grid, lds, s, bf, lds_bf); break;
+      case 4: rc = launch_lift_cs<4>(mp, p->sc.KP, grid, lds, s, bf, lds_bf); break;
+      case 5: rc = launch_lift_cs<5>(mp, p->sc.KP, grid, lds, s, bf, lds_bf); break;
+      case 6: rc = launch_lift_cs<6>(mp, p->sc.KP, grid, lds, s, bf, lds_bf); break;
+      case 7: rc = launch_lift_cs<7>(mp, p->sc.KP, grid, lds, s, bf, lds_bf); break;
+      default: rc = launch_lift_cs<8>(mp, p->sc.KP, grid, lds, s, bf, lds_bf); break;
     }
     if (rc != DLWP_OK) return rc;
     if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::LIFT));
@@ -1050,6 +1437,7 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     lp.x = hin; lp.y = hout; lp.wsp = p->wsp[l].as<float>(); lp.bias = p->sbias[l].as<float>();
     lp.zbuf = ws.zbuf; lp.t = p->sc.t.as<float>(); lp.tt = p->sc.tt.as<float>(); lp.ybuf = ws.ybuf;
     lp.B = B; lp.H = p->H; lp.W = p->W;
+    lp.stagger = layer_stagger();
     const bool last = (l == p->L - 1);
     // neuralop FNOBlocks.forward_with_postactivation: GELU after every layer but the last
     if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::LAYER));
@@ -1075,11 +1463,19 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::PROJ));
     if (p->proj_co > 0) {
       mp.w2p = p->proj_w2v.as<float>();
-      const size_t lds2 = ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4;
+      const bool bf = use_bf16x6();
+      if (bf) mp.w1p = p->proj_w1b.as<float>();
+      const size_t lds2 = bf ? ((size_t)nt * 3 * 64 * 4 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4
+                             : ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4;
 #define DLWP_LAUNCH_PROJ(CO_, RES_)                                                                     \
   do {                                                                                                  \
-    DLWP_HIP_CHECK(allow_lds(pw_proj_small_kernel<CO_, RES_>, lds2));                                   \
-    hipLaunchKernelGGL((pw_proj_small_kernel<CO_, RES_>), dim3(grid), dim3(256), lds2, s, mp);          \
+    if (bf) {                                                                                           \
+      DLWP_HIP_CHECK(allow_lds(pw_proj_bf16x6_kernel<CO_, RES_>, lds2));                                \
+      hipLaunchKernelGGL((pw_proj_bf16x6_kernel<CO_, RES_>), dim3((grid + 1) / 2), dim3(512), lds2, s, mp); \
+    } else {                                                                                            \
+      DLWP_HIP_CHECK(allow_lds(pw_proj_small_kernel<CO_, RES_>, lds2));                                 \
+      hipLaunchKernelGGL((pw_proj_small_kernel<CO_, RES_>), dim3(grid), dim3(256), lds2, s, mp);        \
+    }                                                                                                   \
   } while (0)
       if (p->proj_co == 1) { if (resid) DLWP_LAUNCH_PROJ(1, true); else DLWP_LAUNCH_PROJ(1, false); }
       else if (p->proj_co == 2) { if (resid) DLWP_LAUNCH_PROJ(2, true); else DLWP_LAUNCH_PROJ(2, false); }
@@ -1098,6 +1494,12 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
   return DLWP_OK;
 }
 }  // namespace
+
+extern "C" int32_t dlwp_set_fp32_mfma(int32_t on) {
+  const int32_t prev = use_bf16x6() ? 0 : 1;
+  g_fp32_mfma = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" size_t dlwp_fno2d_workspace_bytes(const dlwp_fno2d_plan* plan, int32_t batch) {
   if (!plan || batch <= 0) return 0;
@@ -1291,5 +1693,6 @@ extern "C" int32_t dlwp_spectral_conv2d_f32(const dlwp_spectral_plan* plan, cons
   lp.x = x; lp.y = y; lp.wsp = nullptr; lp.bias = plan->zero_bias.as<float>(); lp.zbuf = zbuf;
   lp.t = sc.t.as<float>(); lp.tt = sc.tt.as<float>(); lp.ybuf = nullptr;
   lp.B = batch; lp.H = sc.H; lp.W = sc.W;
+  lp.stagger = 0;
   return launch_layer<false, false, false>(sc, lp, s);
 }

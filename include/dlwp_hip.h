@@ -42,6 +42,13 @@ const char* dlwp_last_error(void);
 /* number of visible HIP devices (<0 on error); does not create a context */
 int32_t dlwp_device_count(void);
 
+/* The channel-MLP GEMMs of the FNO path run by default as "bf16x6": each fp32 operand is split
+ * exactly into three bf16 parts and the six significant cross products are accumulated in fp32 on the
+ * bf16 matrix pipe (fp32-GEMM accuracy).  on != 0 selects the plain fp32 MFMA
+ * kernels instead (A/B measurements, numerical cross-check).  Process-wide; returns the previous
+ * setting.  Environment: DLWP_FP32_MFMA=1 has the same effect. */
+int32_t dlwp_set_fp32_mfma(int32_t on);
+
 /* ------------------------------------------------------------------------------------------
  * FNO2d rollout  (reference models/fno/fno.py:12-106 `FNO2DModule`; the arithmetic it delegates
  * to neuralop.models.FNO -- fno.py:38-47 -- is restated in DESIGN.md / oracle/restate/fno.py)

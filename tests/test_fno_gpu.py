@@ -148,3 +148,29 @@ def test_fno_argument_errors():
         hip(prognostic=torch.zeros(1, 3, 2, 64, 64, device=_dev()))      # wrong channel count
     with pytest.raises(L.DlwpError):
         hip(prognostic=torch.zeros(1, 3, 1, 64, 48, device=_dev()))      # unsupported width
+
+
+def test_bf16x6_matches_fp32_mfma_kernels():
+    """The default MLP kernels compute fp32 GEMMs as six bf16 MFMAs (bf16x6 split, fp32 accumulate);
+    the plain fp32-MFMA kernels are the cross-check: both must agree with each other far below the
+    parity tolerance, and both with the oracle."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    ref, hip = _make_pair(**NS_KW)
+    _, _, prog = navier_stokes(4, 6)
+    p = prog.to(_dev())
+    lib = L.load()
+    prev = lib.dlwp_set_fp32_mfma(0)
+    try:
+        a = hip(prognostic=p)
+        lib.dlwp_set_fp32_mfma(1)
+        b = hip(prognostic=p)
+    finally:
+        lib.dlwp_set_fp32_mfma(prev)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = ref(prognostic=prog)
+    assert max(per_step_rel_l2(a, b)) < 2e-6
+    assert max(per_step_rel_l2(a, want)) <= TOL
+    assert max(per_step_rel_l2(b, want)) <= TOL
