@@ -83,17 +83,30 @@ __device__ __forceinline__ int pack_info(const Coord& c) {
   return (c.zpl & 0xF) | ((c.zlat & 0xFF) << 4) | ((c.zlon & 0xFF) << 12) | ((c.region & 0x1F) << 20);
 }
 
-// DT = head_dim / 4 (k-steps of the QK^T product), DB = ceil(head_dim / 16) (16-row blocks of O^T)
-// SUB = 16-query sub-tiles per wave.  Block = 4 waves = 64*SUB queries of one (batch, window, head).
-template <int DT, int DB, int SUB>
-__global__ __launch_bounds__(256) void window_attn_f32_kernel(const Desc D, const float* __restrict__ qkv,
-                                                              const float* __restrict__ qkv_bias,
-                                                              const float* __restrict__ table,
-                                                              float* __restrict__ out, long long L) {
+// DT = head_dim / 4, DB = ceil(head_dim / 16) (16-row blocks of O^T), SUB = 16-query sub-tiles per wave.
+// Block = 4 waves = 64*SUB queries of one (batch, window, head); keys stream through LDS in tiles of 32.
+//
+// BF16 = false: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32 products; the parity path).
+// BF16 = true : Q, K, V and P rounded to bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation and fp32
+//               softmax statistics; head_dim is one (<= 32) or two k-steps deep, so a 32-key x 16-query
+//               tile costs 2-4 + DB matrix instructions instead of 2*DT + 8*DB.
+// LON4: the window's fastest axis is a multiple of 4, so the 4 keys a lane owns in a 16-key block
+//       (rows 4g..4g+3 of the accumulator) are consecutive along longitude: ONE bias index per 4 scores.
+// All score arithmetic is in the log2 domain (q scale, bias table and mask are pre-multiplied by
+// log2 e) so the softmax exponentials are bare v_exp_f32.
+template <int DT, int DB, int SUB, bool BF16, bool LON4>
+__global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const float* __restrict__ qkv,
+                                                          const float* __restrict__ qkv_bias,
+                                                          const float* __restrict__ table,
+                                                          float* __restrict__ out, long long L) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int KT = 32;                 // keys per tile
-  constexpr int LDK = 4 * DT + 2;        // K tile row stride (floats): conflict-free A-operand reads
-  constexpr int LDV = 16 * DB + 4;       // V tile row stride
+  constexpr int KT = 32;                       // keys per tile
+  constexpr int LDK = 4 * DT + 2;              // fp32 K tile row stride (floats)
+  constexpr int LDV = 16 * DB + 4;             // fp32 V tile row stride
+  constexpr int DK = (4 * DT + 31) / 32;       // bf16: k-steps of 32 over head_dim
+  constexpr int LDKB = 32 * DK + 8;            // bf16 K tile row stride (bf16 elements), 16-byte aligned rows
+  constexpr int LDVB = KT + 8;                 // bf16 V^T tile row stride (bf16 elements)
+  constexpr float LOG2E = 1.4426950408889634f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int head = blockIdx.y;
@@ -106,39 +119,53 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(const Desc D, cons
   const int ipl = t2 % D.npl, ilon = t2 / D.npl;
   const int d = D.d, C = D.C, N = D.N;
 
-  float* s_tab = smem;                          // [table_rows] bias column of this (type, head)
-  float* s_k = s_tab + ((D.table_rows + 3) & ~3);  // [KT][LDK]
-  float* s_v = s_k + KT * LDK;                  // [KT][LDV]
-  int* s_info = reinterpret_cast<int*>(s_v + KT * LDV);  // [KT] packed key coords (+ -1 beyond N)
+  float* s_tab = smem;                                   // [table_rows] bias column * log2 e
+  float* s_kv = s_tab + ((D.table_rows + 3) & ~3);       // K / V tiles (layout depends on BF16)
+  float* s_k = s_kv;                                     // fp32: [KT][LDK]
+  float* s_v = s_k + KT * LDK;                           // fp32: [KT][LDV]
+  unsigned short* s_kb = reinterpret_cast<unsigned short*>(s_kv);   // bf16: [KT][LDKB]
+  unsigned short* s_vb = s_kb + KT * LDKB;                          // bf16: [16*DB][LDVB]  (V transposed)
+  constexpr int KV_FLOATS = BF16 ? (KT * LDKB + 16 * DB * LDVB + 1) / 2 : KT * (LDK + LDV);
+  int* s_info = reinterpret_cast<int*>(s_kv + ((KV_FLOATS + 3) & ~3));  // [KT] packed key coords, -1 beyond N
 
-  {  // bias column -> LDS
+  {
     const int type = ipl * D.nlat + ilat;
     const long long stride = D.bias_mode ? (long long)D.types * D.heads : D.heads;
     const float* col = table + (D.bias_mode ? (long long)type * D.heads : 0) + head;
-    for (int i = tid; i < D.table_rows; i += 256) s_tab[i] = col[i * stride];
+    for (int i = tid; i < D.table_rows; i += 256) s_tab[i] = col[i * stride] * LOG2E;
   }
 
   const float* qkv_b = qkv + (long long)b * L * 3 * C;
   const int q_base = blockIdx.x * (64 * SUB) + wave * (16 * SUB);
-  // Q^T operands (B operand: B[k = g][col = query j]) pre-scaled; query coordinates per lane column
-  float qreg[SUB][DT];
+  const float qscale = D.scale * LOG2E;
+  float qreg[BF16 ? 1 : SUB][BF16 ? 1 : DT];      // fp32 path: B[k = g][col j] per k-step
+  u32x4 qb[BF16 ? SUB : 1][BF16 ? DK : 1];         // bf16 path: 8 consecutive head dims per k-step
   int qinfo[SUB];
 #pragma unroll
   for (int sub = 0; sub < SUB; ++sub) {
     const int qn = q_base + 16 * sub + j;
-    if (qn < N) {
-      const Coord c = token_coord(D, ipl, ilat, ilon, qn);
+    Coord c;
+    c.src = -1;
+    qinfo[sub] = 0;
+    const bool live = qn < N;
+    if (live) {
+      c = token_coord(D, ipl, ilat, ilon, qn);
       qinfo[sub] = pack_info(c);
+    }
+    const float* src = (live && c.src >= 0) ? qkv_b + c.src * 3 * C + head * d : qkv_bias + head * d;
+    if constexpr (!BF16) {
 #pragma unroll
-      for (int s = 0; s < DT; ++s) {
-        const int e = 4 * s + g;
-        const float v = (c.src >= 0) ? qkv_b[c.src * 3 * C + head * d + e] : qkv_bias[head * d + e];
-        qreg[sub][s] = v * D.scale;
-      }
+      for (int s = 0; s < DT; ++s) qreg[sub][s] = live ? src[4 * s + g] * qscale : 0.f;
     } else {
-      qinfo[sub] = 0;
 #pragma unroll
-      for (int s = 0; s < DT; ++s) qreg[sub][s] = 0.f;
+      for (int ks = 0; ks < DK; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = 32 * ks + 8 * g + 2 * i;
+          const float v0 = (live && e < d) ? src[e] * qscale : 0.f;
+          const float v1 = (live && e + 1 < d) ? src[e + 1] * qscale : 0.f;
+          qb[sub][ks][i] = cvt_pk_bf16(v0, v1);
+        }
     }
   }
 
@@ -151,107 +178,163 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(const Desc D, cons
 #pragma unroll
     for (int db = 0; db < DB; ++db) oacc[sub][db] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const float mask_val = -100.0f * LOG2E;
 
   const int ntile = (N + KT - 1) / KT;
   for (int kt = 0; kt < ntile; ++kt) {
     __syncthreads();
-    // stage K, V (zero-filled beyond head_dim) and key info for keys kt*32 .. +31
-    for (int i = tid; i < KT * 4 * DT; i += 256) {
-      const int key = i / (4 * DT), e = i % (4 * DT);
-      const int kn = kt * KT + key;
-      float kv = 0.f, vv = 0.f;
-      if (kn < N) {
-        const Coord c = token_coord(D, ipl, ilat, ilon, kn);
-        if (e == 0) s_info[key] = pack_info(c);
-        if (c.src >= 0) {
-          kv = qkv_b[c.src * 3 * C + C + head * d + e];
-          vv = qkv_b[c.src * 3 * C + 2 * C + head * d + e];
-        } else {
-          kv = qkv_bias[C + head * d + e];
-          vv = qkv_bias[2 * C + head * d + e];
+    // ---- stage keys kt*32 .. +31: K, V (converted / transposed for the bf16 path) and key info
+    if constexpr (!BF16) {
+      for (int i = tid; i < KT * 4 * DT; i += 256) {
+        const int key = i / (4 * DT), e = i % (4 * DT);
+        const int kn = kt * KT + key;
+        float kv = 0.f, vv = 0.f;
+        if (kn < N) {
+          const Coord c = token_coord(D, ipl, ilat, ilon, kn);
+          if (e == 0) s_info[key] = pack_info(c);
+          const float* src = c.src >= 0 ? qkv_b + c.src * 3 * C + head * d : qkv_bias + head * d;
+          kv = src[C + e];
+          vv = src[2 * C + e];
+        } else if (e == 0) {
+          s_info[key] = -1;
         }
-      } else if (e == 0) {
-        s_info[key] = -1;
+        s_k[key * LDK + e] = kv;
+        s_v[key * LDV + e] = vv;
       }
-      s_k[key * LDK + e] = kv;
-      s_v[key * LDV + e] = vv;
-    }
-    if (16 * DB > 4 * DT) {  // zero the pad columns of V (head_dim not a multiple of 16)
-      for (int i = tid; i < KT * (16 * DB - 4 * DT); i += 256) {
-        const int key = i / (16 * DB - 4 * DT), e = 4 * DT + i % (16 * DB - 4 * DT);
-        s_v[key * LDV + e] = 0.f;
+      if (16 * DB > 4 * DT) {
+        for (int i = tid; i < KT * (16 * DB - 4 * DT); i += 256) {
+          const int key = i / (16 * DB - 4 * DT), e = 4 * DT + i % (16 * DB - 4 * DT);
+          s_v[key * LDV + e] = 0.f;
+        }
+      }
+    } else {
+      constexpr int EP = 16 * DK;  // element pairs per key row (head dims padded to 32*DK)
+      for (int i = tid; i < KT * EP; i += 256) {
+        const int key = i / EP, e = 2 * (i % EP);
+        const int kn = kt * KT + key;
+        float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
+        if (kn < N) {
+          const Coord c = token_coord(D, ipl, ilat, ilon, kn);
+          if (e == 0) s_info[key] = pack_info(c);
+          const float* src = c.src >= 0 ? qkv_b + c.src * 3 * C + head * d : qkv_bias + head * d;
+          if (e < d) { k0 = src[C + e]; v0 = src[2 * C + e]; }
+          if (e + 1 < d) { k1 = src[C + e + 1]; v1 = src[2 * C + e + 1]; }
+        } else if (e == 0) {
+          s_info[key] = -1;
+        }
+        *reinterpret_cast<unsigned*>(s_kb + key * LDKB + e) = cvt_pk_bf16(k0, k1);
+        if (e < 16 * DB) {
+          const unsigned vp = cvt_pk_bf16(v0, v1);
+          s_vb[e * LDVB + key] = (unsigned short)(vp & 0xFFFFu);
+          s_vb[(e + 1) * LDVB + key] = (unsigned short)(vp >> 16);
+        }
       }
     }
     __syncthreads();
 
 #pragma unroll
     for (int sub = 0; sub < SUB; ++sub) {
-      // S^T[key][query] for the two 16-key blocks of the tile
+      // ---- S^T[key][query] for the two 16-key blocks of the tile
       f32x4 sc[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         sc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!BF16) {
 #pragma unroll
-        for (int s = 0; s < DT; ++s) sc[kb] = mfma16x16x4(s_k[(kb * 16 + j) * LDK + 4 * s + g], qreg[sub][s], sc[kb]);
+          for (int s = 0; s < DT; ++s) sc[kb] = mfma16x16x4(s_k[(kb * 16 + j) * LDK + 4 * s + g], qreg[sub][s], sc[kb]);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < DK; ++ks) {
+            const u32x4 ka = *reinterpret_cast<const u32x4*>(s_kb + (kb * 16 + j) * LDKB + 32 * ks + 8 * g);
+            sc[kb] = mfma16x16x32_bf16(ka, qb[sub][ks], sc[kb]);
+          }
+        }
       }
-      // bias + mask: this lane's query is column j, its keys are rows 4g + r of each block
+      // ---- bias + mask (log2 domain): this lane's query is column j, its keys are rows 4g + r
       const int qi = qinfo[sub];
       const int qpl = qi & 0xF, qlat = (qi >> 4) & 0xFF, qlon = (qi >> 12) & 0xFF, qreg_id = (qi >> 20) & 0x1F;
       float mx = -1e30f;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb) {
+        const int4 ki4 = *reinterpret_cast<const int4*>(s_info + kb * 16 + 4 * g);
+        const int kia[4] = {ki4.x, ki4.y, ki4.z, ki4.w};
+        int idx0 = 0;
+        if (LON4) {
+          const int ki = kia[0];
+          const int kpl = ki & 0xF, klat = (ki >> 4) & 0xFF, klon = (ki >> 12) & 0xFF;
+          idx0 = D.bias_mode == 0
+                     ? (qlat - klat + D.wlat - 1) * (2 * D.wlon - 1) + (qlon - klon + D.wlon - 1)
+                     : ((qpl + kpl * D.wpl) * D.wlat * D.wlat + (qlat + klat * D.wlat)) * (2 * D.wlon - 1) +
+                           (qlon - klon + D.wlon - 1);
+          if (ki < 0) idx0 = 3;  // keep the speculative reads below in bounds
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ki = s_info[kb * 16 + 4 * g + r];
-          float v;
-          if (ki < 0) {
-            v = -1e30f;
+          const int ki = kia[r];
+          int idx;
+          if (LON4) {
+            idx = idx0 - r;
           } else {
-            const int kpl = ki & 0xF, klat = (ki >> 4) & 0xFF, klon = (ki >> 12) & 0xFF, kreg = (ki >> 20) & 0x1F;
-            int idx;
-            if (D.bias_mode == 0) {
-              idx = (qlat - klat + D.wlat - 1) * (2 * D.wlon - 1) + (qlon - klon + D.wlon - 1);
-            } else {
-              idx = ((qpl + kpl * D.wpl) * D.wlat * D.wlat + (qlat + klat * D.wlat)) * (2 * D.wlon - 1) +
-                    (qlon - klon + D.wlon - 1);
-            }
-            v = sc[kb][r] + s_tab[idx];
-            if (D.use_mask && kreg != qreg_id) v += -100.0f;
+            const int kpl = ki & 0xF, klat = (ki >> 4) & 0xFF, klon = (ki >> 12) & 0xFF;
+            idx = D.bias_mode == 0
+                      ? (qlat - klat + D.wlat - 1) * (2 * D.wlon - 1) + (qlon - klon + D.wlon - 1)
+                      : ((qpl + kpl * D.wpl) * D.wlat * D.wlat + (qlat + klat * D.wlat)) * (2 * D.wlon - 1) +
+                            (qlon - klon + D.wlon - 1);
+            if (ki < 0) idx = 0;
           }
+          float v = sc[kb][r] + s_tab[idx];
+          if (D.use_mask && ((ki >> 20) & 0x1F) != qreg_id) v += mask_val;
+          v = ki < 0 ? -1e30f : v;
           sc[kb][r] = v;
           mx = fmaxf(mx, v);
         }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run[sub], mx);
-      const float alpha = __expf(m_run[sub] - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_new);
       m_run[sub] = m_new;
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pexp = __expf(sc[kb][r] - m_new);
+          const float pexp = __builtin_amdgcn_exp2f(sc[kb][r] - m_new);
           sc[kb][r] = pexp;
           psum += pexp;
         }
       l_run[sub] = l_run[sub] * alpha + psum;
 #pragma unroll
       for (int db = 0; db < DB; ++db) oacc[sub][db] *= alpha;
-      // O^T[dim][query] += V^T[dim][key] P^T[key][query]; P^T rows (keys) = 4g + r = accumulator rows
+      // ---- O^T[dim][query] += V^T[dim][key] P^T[key][query]; the keys a lane holds (accumulator rows
+      // 4g + r of the two blocks) are exactly the k-slots it supplies: no lane movement
+      if constexpr (!BF16) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int db = 0; db < DB; ++db)
-            oacc[sub][db] = mfma16x16x4(s_v[(kb * 16 + 4 * g + r) * LDV + 16 * db + j], sc[kb][r], oacc[sub][db]);
+            for (int db = 0; db < DB; ++db)
+              oacc[sub][db] = mfma16x16x4(s_v[(kb * 16 + 4 * g + r) * LDV + 16 * db + j], sc[kb][r], oacc[sub][db]);
+      } else {
+        // k-slot jj of lane group g: jj < 4 -> key 4g + jj, jj >= 4 -> key 16 + 4g + (jj - 4)
+        const u32x4 pb = {cvt_pk_bf16(sc[0][0], sc[0][1]), cvt_pk_bf16(sc[0][2], sc[0][3]),
+                          cvt_pk_bf16(sc[1][0], sc[1][1]), cvt_pk_bf16(sc[1][2], sc[1][3])};
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const unsigned short* vr = s_vb + (16 * db + j) * LDVB + 4 * g;
+          const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+          const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+          const u32x4 va = {lo.x, lo.y, hi.x, hi.y};
+          oacc[sub][db] = mfma16x16x32_bf16(va, pb, oacc[sub][db]);
+        }
+      }
     }
   }
 
-  // epilogue: normalise, transpose through LDS (reuse the K/V tile area) and store whole rows
+  // ---- epilogue: normalise, transpose through LDS (reusing the K/V tile area), store whole rows
   __syncthreads();
-  float* s_o = s_k;  // [64*SUB queries][16*DB + 1]
+  float* s_o = s_kv;  // [64*SUB queries][16*DB + 1]
   constexpr int LDO = 16 * DB + 1;
 #pragma unroll
   for (int sub = 0; sub < SUB; ++sub) {
@@ -283,35 +366,44 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(const Desc D, cons
 using namespace dlwp;
 using namespace dlwp::wattn;
 
-template <int DT, int DB>
-static int32_t launch_wattn(const Desc& D, const float* qkv, const float* qkv_bias, const float* table, float* out,
-                            int batch, long long L, hipStream_t s) {
+template <int DT, int DB, int SUB, bool BF16, bool LON4>
+static int32_t launch_wattn_k(const Desc& D, const float* qkv, const float* qkv_bias, const float* table, float* out,
+                              int batch, long long L, hipStream_t s) {
   const int nwin = D.npl * D.nlat * D.nlon;
-  constexpr int KT = 32, LDK = 4 * DT + 2, LDV = 16 * DB + 4;
-  const bool big = D.N >= 512;
-  const int sub = big ? 2 : 1;
-  size_t lds = (size_t)(((D.table_rows + 3) & ~3) + KT * LDK + KT * LDV) * 4 + KT * 4;
-  const size_t epi = (size_t)(((D.table_rows + 3) & ~3)) * 4 + (size_t)64 * sub * (16 * DB + 1) * 4;
+  constexpr int KT = 32, LDK = 4 * DT + 2, LDV = 16 * DB + 4, DK = (4 * DT + 31) / 32, LDKB = 32 * DK + 8, LDVB = KT + 8;
+  constexpr int KV_FLOATS = BF16 ? (KT * LDKB + 16 * DB * LDVB + 1) / 2 : KT * (LDK + LDV);
+  const size_t tab = (size_t)((D.table_rows + 3) & ~3);
+  size_t lds = (tab + ((KV_FLOATS + 3) & ~3) + KT) * 4;
+  const size_t epi = (tab + (size_t)64 * SUB * (16 * DB + 1)) * 4;
   if (epi > lds) lds = epi;
   DLWP_REQUIRE(lds <= 160 * 1024, DLWP_ERR_UNSUPPORTED, "window attention needs %zu bytes of LDS (bias table too large)", lds);
-  const dim3 grid((D.N + 64 * sub - 1) / (64 * sub), D.heads, batch * nwin);
-  if (big) {
-    if (lds > 48 * 1024)
-      DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_f32_kernel<DT, DB, 2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((window_attn_f32_kernel<DT, DB, 2>), grid, dim3(256), lds, s, D, qkv, qkv_bias, table, out, L);
-  } else {
-    if (lds > 48 * 1024)
-      DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_f32_kernel<DT, DB, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((window_attn_f32_kernel<DT, DB, 1>), grid, dim3(256), lds, s, D, qkv, qkv_bias, table, out, L);
-  }
+  const dim3 grid((D.N + 64 * SUB - 1) / (64 * SUB), D.heads, batch * nwin);
+  auto kern = window_attn_kernel<DT, DB, SUB, BF16, LON4>;
+  if (lds > 48 * 1024)
+    DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, D, qkv, qkv_bias, table, out, L);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
 
-extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
-                                        const float* table, float* out, int32_t batch, void* stream) {
+template <int DT, int DB>
+static int32_t launch_wattn(const Desc& D, const float* qkv, const float* qkv_bias, const float* table, float* out,
+                            int batch, long long L, hipStream_t s, bool bf16) {
+  const bool big = D.N >= 512;
+  const bool lon4 = (D.wlon % 4) == 0;
+#define DLWP_WA(SUB_, BF_, L4_) return launch_wattn_k<DT, DB, SUB_, BF_, L4_>(D, qkv, qkv_bias, table, out, batch, L, s)
+  if (bf16) {
+    if (big) { if (lon4) DLWP_WA(2, true, true); else DLWP_WA(2, true, false); }
+    else { if (lon4) DLWP_WA(1, true, true); else DLWP_WA(1, true, false); }
+  } else {
+    if (big) { if (lon4) DLWP_WA(2, false, true); else DLWP_WA(2, false, false); }
+    else { if (lon4) DLWP_WA(1, false, true); else DLWP_WA(1, false, false); }
+  }
+#undef DLWP_WA
+}
+
+static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias, const float* table,
+                                float* out, int32_t batch, void* stream, bool bf16) {
   DLWP_REQUIRE(u && qkv && table && out, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0, DLWP_ERR_INVALID_ARGUMENT, "batch must be positive");
   Desc D;
@@ -356,11 +448,21 @@ extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* q
   const float* qb = qkv_bias ? qkv_bias : qkv;  // never dereferenced when nothing is padded
   switch (D.d / 4) {
 #define DLWP_CASE(DT_) \
-  case DT_: return launch_wattn<DT_, (4 * DT_ + 15) / 16>(D, qkv, qb, table, out, batch, L, s);
+  case DT_: return launch_wattn<DT_, (4 * DT_ + 15) / 16>(D, qkv, qb, table, out, batch, L, s, bf16);
     DLWP_CASE(1) DLWP_CASE(2) DLWP_CASE(3) DLWP_CASE(4) DLWP_CASE(5) DLWP_CASE(6) DLWP_CASE(7) DLWP_CASE(8)
     DLWP_CASE(9) DLWP_CASE(10) DLWP_CASE(11) DLWP_CASE(12) DLWP_CASE(13) DLWP_CASE(14) DLWP_CASE(15) DLWP_CASE(16)
 #undef DLWP_CASE
     default: break;
   }
   return fail(DLWP_ERR_UNSUPPORTED, "head_dim %d not supported", D.d);
+}
+
+extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
+                                        const float* table, float* out, int32_t batch, void* stream) {
+  return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, false);
+}
+
+extern "C" int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
+                                         const float* table, float* out, int32_t batch, void* stream) {
+  return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, true);
 }

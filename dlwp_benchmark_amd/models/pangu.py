@@ -96,6 +96,7 @@ class _EarthSpecificBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = _Mlp(dim, int(dim * 4.0))
         self.roll = bool(self.shift_size[0] and self.shift_size[1] and self.shift_size[2])
+        self.attention_precision = "fp32"
         self.register_buffer("attn_mask", _shift_mask(self.pad_resolution, self.window_size, self.shift_size)
                              if self.roll else None)
 
@@ -116,7 +117,8 @@ class _EarthSpecificBlock(nn.Module):
             mask_b2=(ppl - spl, plat - slat, plon) if self.roll else (ops.BIG,) * 3,
             bias_mode=1, heads=self.num_heads, head_dim=self.dim // self.num_heads, scale=self.attn.scale)
         qkv = self.attn.qkv(self.norm1(x))
-        a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec)
+        a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec,
+                                 precision=self.attention_precision)
         x = x + self.attn.proj(a)
         return x + self.mlp(self.norm2(x))
 
@@ -221,6 +223,13 @@ class PanguWeather(HipBackbone):
         self.upsample = _UpSample(embed_dim * 2, embed_dim, res2, res)
         self.layer4 = _BasicLayer(embed_dim, res, 2, num_heads[3], window_size)
         self.patchrecovery2d = _PatchRecovery2D((n_lat, n_lon), patch_size, 2 * embed_dim, prognostic_channels)
+
+    def set_attention_precision(self, precision: str):
+        """"fp32" (default, parity path) or "bf16" (bf16 MFMA operands, fp32 accumulate / softmax)."""
+        for m in self.modules():
+            if hasattr(m, "attention_precision"):
+                m.attention_precision = precision
+        return self
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:
         """panguweather.py:512-535 (`forward_one_step`)."""

@@ -63,6 +63,7 @@ class _Block(nn.Module):
         self.attn = _WindowAttention(dim, self.window_size, num_heads, qkv_bias, qk_scale)
         self.norm2 = norm_layer(dim)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.attention_precision = "fp32"
 
     def forward(self, x, h, w):
         wh, ww = self.window_size
@@ -78,7 +79,8 @@ class _Block(nn.Module):
             mask_b1=(ops.BIG, h - wh, w - ww), mask_b2=(ops.BIG, h - wh // 2, w - ww // 2),
             bias_mode=0, heads=self.num_heads, head_dim=self.dim // self.num_heads, scale=self.attn.scale)
         qkv = self.attn.qkv(self.norm1(x))
-        a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.relative_position_bias_table, spec)
+        a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.relative_position_bias_table, spec,
+                                 precision=self.attention_precision)
         x = x + self.attn.proj(a)
         return x + self.mlp(self.norm2(x))
 
@@ -177,6 +179,13 @@ class SwinTransformer(HipBackbone):
 
     def train(self, mode: bool = True):
         super().train(mode)
+        return self
+
+    def set_attention_precision(self, precision: str):
+        """"fp32" (default, parity path) or "bf16" (bf16 MFMA operands, fp32 accumulate / softmax)."""
+        for m in self.modules():
+            if hasattr(m, "attention_precision"):
+                m.attention_precision = precision
         return self
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:

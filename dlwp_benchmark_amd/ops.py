@@ -42,8 +42,11 @@ class WindowSpec:
 
 
 def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table: torch.Tensor,
-                     spec: WindowSpec) -> torch.Tensor:
-    """qkv [B, L, 3*C] (qkv Linear output, un-padded token order) -> [B, L, C]."""
+                     spec: WindowSpec, precision: str = "fp32") -> torch.Tensor:
+    """qkv [B, L, 3*C] (qkv Linear output, un-padded token order) -> [B, L, C].
+    precision "fp32": exact fp32 products (parity path); "bf16": bf16 MFMA operands, fp32 accumulate."""
+    if precision not in ("fp32", "bf16"):
+        raise _lib.DlwpError(f"unknown attention precision {precision!r}")
     _lib.require_cuda_tensor(qkv, "qkv")
     _lib.require_cuda_tensor(table, "bias table")
     _lib.require_cuda_tensor(qkv_bias, "qkv bias")
@@ -57,10 +60,10 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table:
     lib = _lib.load()
     d = spec.to_c()
     with torch.cuda.device(qkv.device):
-        _lib.check(lib.dlwp_window_attn_f32(ctypes.byref(d), qkv.data_ptr(),
-                                            qkv_bias.contiguous().data_ptr() if qkv_bias is not None else None,
-                                            table.data_ptr(), out.data_ptr(), b, _lib.stream_ptr()),
-                   "dlwp_window_attn_f32")
+        fn = lib.dlwp_window_attn_bf16 if precision == "bf16" else lib.dlwp_window_attn_f32
+        _lib.check(fn(ctypes.byref(d), qkv.data_ptr(),
+                      qkv_bias.contiguous().data_ptr() if qkv_bias is not None else None,
+                      table.data_ptr(), out.data_ptr(), b, _lib.stream_ptr()), "dlwp_window_attn_" + precision)
     return out
 
 

@@ -185,6 +185,12 @@ typedef struct dlwp_wattn_desc {
 int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* desc, const float* qkv_dev,
                              const float* qkv_bias_dev, const float* table_dev, float* out_dev,
                              int32_t batch, void* stream);
+/* Same interface (fp32 tensors in and out); Q, K, V and the softmax probabilities are rounded to bf16
+ * and both products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation and fp32 softmax statistics
+ * (the precision BASELINE.json names for the Swin / Pangu configs). */
+int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* desc, const float* qkv_dev,
+                              const float* qkv_bias_dev, const float* table_dev, float* out_dev,
+                              int32_t batch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * AFNO2D frequency-domain mixing (reference models/fourcastnet/fourcastnet.py:87-121): complex

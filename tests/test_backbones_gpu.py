@@ -53,3 +53,29 @@ def test_rollout_matches_reference_golden(tag):
     assert got.shape == want.shape
     errs = per_step_rel_l2(got, want)
     assert max(errs) <= TOL, f"{tag}: per-step rel L2 {['%.2e' % e for e in errs]}"
+
+
+@pytest.mark.parametrize("tag", ["swin_e32_32x64", "pangu_e48_32x64"])
+def test_bf16_attention_stays_close_to_reference(tag):
+    """bf16-MFMA window attention (the precision BASELINE.json names for the Swin / Pangu configs):
+    Q, K, V, P rounded to bf16, fp32 accumulation and softmax statistics.  Stated bound: per-step
+    relative L2 of the rollout <= 5e-3 against the fp32 reference trajectory."""
+    import dlwp_benchmark_amd.models as M
+    from dlwp_benchmark_amd.weights import fill_by_spec
+    from oracle.make_golden import MODEL_CASES, model_inputs
+
+    family, cfg, (batch, frames), gain = MODEL_CASES[tag]
+    name, _ = _product_class(family)
+    g = load_golden(f"model_{tag}")
+    sd, _ = fill_by_spec(json.loads(str(g["param_spec"])), gain=gain)
+    model = getattr(M, name)(**cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to("cuda:0").eval().set_attention_precision("bf16")
+    constants, prescribed, prognostic = model_inputs(tag, cfg, batch, frames)
+    dev = lambda t: t.to("cuda:0") if t is not None else None
+    got = model(constants=dev(constants), prescribed=dev(prescribed), prognostic=dev(prognostic))
+    torch.cuda.synchronize()
+    errs = per_step_rel_l2(got, torch.from_numpy(g["y"]))
+    print(tag, "bf16 attention per-step rel L2:", ["%.2e" % e for e in errs])
+    assert max(errs) <= 5e-3, errs
+    assert max(errs) > 1e-7, "bf16 path suspiciously exact: is it running?"
