@@ -82,86 +82,44 @@ __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
 }
 
 // GELU (exact, erf form: torch.nn.functional.gelu default) without a libm call.
-//   gelu(x) = 0.5 x (1 + erf(x/sqrt2)) = max(x, 0) - 0.5 |x| erfc(|x|/sqrt2)
-//   erfc(t), t >= 0, is evaluated as exp2(t * P(t)) with a degree-8 polynomial fitted to
-//   -log2(erfc(t))/t on [0, 4.5] (t clamped there: erfc(4.5) = 2e-10).  Max abs error of the
-//   GELU value 1.7e-7 (fp32 round-off level of the exp), see tests/test_gelu_poly.py.
-// The fp32 matrix instructions run on the same fp32 lanes as the VALU (they do not overlap), so
-// GELU issue slots are as expensive as MFMA cycles: the pair form below uses packed fp32
-// (v_pk_fma_f32 / v_pk_mul_f32) and costs ~10 issue slots per element instead of ~19.
+//   gelu(x) = 0.5 x (1 + erf(x/sqrt2)) = max(x, 0) - |x| * (0.5 erfc(|x|/sqrt2))
+//   0.5 erfc(u/sqrt2), u >= 0, is evaluated as exp2(u * Q(u) - 1) with a degree-8 polynomial (fitted to
+//   -log2(erfc(t))/t on t in [0, 4.5] and re-expressed in u = sqrt2 t; u clamped at 4.5 sqrt2, where
+//   erfc = 2e-10).  Max abs error of the GELU value 2.6e-7 in fp32 (tests/test_gelu_poly.py).
+// The fp32 matrix instructions run on the same fp32 lanes as the VALU (they do not overlap,
+// tools/ubench_fp32.hip), so GELU issue slots are as expensive as MFMA cycles: the 8-wide form below
+// uses packed fp32 and costs ~8.5 issue slots per element (libm-free scalar code: ~19).
+#define DLWP_GELU_UMAX 6.3639610306789276f
+#define DLWP_GELU_Q8 2.493533486e-07f
 #define DLWP_GELU_COEFFS(X)                                                                    \
-  X(5.642222277e-06f) X(-9.264355322e-05f) X(6.046944181e-04f) X(-1.767261187e-03f)            \
-  X(-5.040322430e-04f) X(2.810628898e-02f) X(-1.484391242e-01f) X(-9.184220433e-01f)           \
-  X(-1.627908349e+00f)
+  X(-5.790222076e-06f) X(5.344793681e-05f) X(-2.209076483e-04f) X(-8.910115139e-05f)           \
+  X(7.026572246e-03f) X(-5.248115212e-02f) X(-4.592110217e-01f) X(-1.151105046e+00f)
 
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float t = fminf(fabsf(x) * 0.70710678118654752f, 4.5f);
-  float p = 0.f;
-#define DLWP_STEP(c) p = fmaf(p, t, c);
+  const float u = fminf(fabsf(x), DLWP_GELU_UMAX);
+  float p = DLWP_GELU_Q8;
+#define DLWP_STEP(c) p = fmaf(p, u, c);
   DLWP_GELU_COEFFS(DLWP_STEP)
 #undef DLWP_STEP
-  const float e = __builtin_amdgcn_exp2f(p * t);  // erfc(|x|/sqrt2)
-  return fmaf(fabsf(x), -0.5f * e, fmaxf(x, 0.f));
+  const float e = __builtin_amdgcn_exp2f(fmaf(p, u, -1.0f));  // 0.5 erfc(|x|/sqrt2)
+  return fmaf(-fabsf(x), e, fmaxf(x, 0.f));
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Pair form, written with explicit gfx950 instructions so that the polynomial really is 8 packed
-// FMAs (hipcc splits a C-level f32x2 Horner chain back into scalar v_fma_f32 and adds canonicalising
-// v_max in front of fmaxf on MFMA outputs): 20 VALU issue slots per PAIR.
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  float t0, t1, e0, e1, m0, m1, r0, r1;
-  const float x0 = x.x, x1 = x.y;
-  asm("v_mul_f32_e64 %0, |%1|, %2" : "=v"(t0) : "v"(x0), "s"(0.70710678118654752f));
-  asm("v_mul_f32_e64 %0, |%1|, %2" : "=v"(t1) : "v"(x1), "s"(0.70710678118654752f));
-  asm("v_min_f32_e32 %0, 0x40900000, %1" : "=v"(t0) : "v"(t0));  // min(t, 4.5)
-  asm("v_min_f32_e32 %0, 0x40900000, %1" : "=v"(t1) : "v"(t1));
-  const f32x2 t = {t0, t1};
-  f32x2 p = {5.642222277e-06f, 5.642222277e-06f};
-#define DLWP_PKSTEP(c)                                                                         \
-  {                                                                                            \
-    const f32x2 cc = {c, c};                                                                   \
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(t), "s"(cc));                    \
-  }
-  DLWP_PKSTEP(-9.264355322e-05f) DLWP_PKSTEP(6.046944181e-04f) DLWP_PKSTEP(-1.767261187e-03f)
-  DLWP_PKSTEP(-5.040322430e-04f) DLWP_PKSTEP(2.810628898e-02f) DLWP_PKSTEP(-1.484391242e-01f)
-  DLWP_PKSTEP(-9.184220433e-01f) DLWP_PKSTEP(-1.627908349e+00f)
-#undef DLWP_PKSTEP
-  f32x2 a;
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(a) : "v"(p), "v"(t));
-  const float a0 = a.x, a1 = a.y;
-  asm("v_exp_f32_e32 %0, %1" : "=v"(e0) : "v"(a0));
-  asm("v_exp_f32_e32 %0, %1" : "=v"(e1) : "v"(a1));
-  f32x2 e = {e0, e1};
-  {
-    const f32x2 mh = {-0.5f, -0.5f};
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(e) : "v"(e), "s"(mh));
-  }
-  const float eh0 = e.x, eh1 = e.y;
-  asm("v_max_f32_e32 %0, 0, %1" : "=v"(m0) : "v"(x0));
-  asm("v_max_f32_e32 %0, 0, %1" : "=v"(m1) : "v"(x1));
-  asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(r0) : "v"(x0), "v"(eh0), "v"(m0));
-  asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(r1) : "v"(x1), "v"(eh1), "v"(m1));
-  return f32x2{r0, r1};
-}
 
 // GELU of two accumulator fragments (8 values): four packed chains interleaved statement by
 // statement.  gfx950 needs two wait states between a packed-fp32 op and a dependent VALU op; with
 // fewer than three independent instructions in between hipcc pads with s_nop, each of which costs
 // a full issue slot on the (shared) fp32 pipe.  volatile keeps the hand interleave.
-#define DLWP_A4(stmt_a, stmt_b, stmt_c, stmt_d) stmt_a stmt_b stmt_c stmt_d
 __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
   const float x0 = u[0], x1 = u[1], x2 = u[2], x3 = u[3], x4 = v[0], x5 = v[1], x6 = v[2], x7 = v[3];
   float t0, t1, t2, t3, t4, t5, t6, t7;
-  const float c = 0.70710678118654752f;
-#define DLWP_T(t, x) asm volatile("v_mul_f32_e64 %0, |%1|, %2" : "=v"(t) : "v"(x), "s"(c));
+  const float umax = DLWP_GELU_UMAX;
+#define DLWP_T(t, x) asm volatile("v_min_f32_e64 %0, |%1|, %2" : "=v"(t) : "v"(x), "s"(umax));
   DLWP_T(t0, x0) DLWP_T(t2, x2) DLWP_T(t4, x4) DLWP_T(t6, x6) DLWP_T(t1, x1) DLWP_T(t3, x3) DLWP_T(t5, x5) DLWP_T(t7, x7)
 #undef DLWP_T
-#define DLWP_M(t) asm volatile("v_min_f32_e32 %0, 0x40900000, %1" : "=v"(t) : "v"(t));
-  DLWP_M(t0) DLWP_M(t2) DLWP_M(t4) DLWP_M(t6) DLWP_M(t1) DLWP_M(t3) DLWP_M(t5) DLWP_M(t7)
-#undef DLWP_M
   const f32x2 ta = {t0, t1}, tb = {t2, t3}, tc = {t4, t5}, td = {t6, t7};
-  f32x2 pa = {5.642222277e-06f, 5.642222277e-06f}, pb = pa, pc = pa, pd = pa;
+  f32x2 pa = {DLWP_GELU_Q8, DLWP_GELU_Q8}, pb = pa, pc = pa, pd = pa;
 #define DLWP_PKSTEP4(cf)                                                                       \
   {                                                                                            \
     const f32x2 cc = {cf, cf};                                                                 \
@@ -170,43 +128,27 @@ __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pc) : "v"(pc), "v"(tc), "s"(cc));        \
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pd) : "v"(pd), "v"(td), "s"(cc));        \
   }
-  DLWP_PKSTEP4(-9.264355322e-05f) DLWP_PKSTEP4(6.046944181e-04f) DLWP_PKSTEP4(-1.767261187e-03f)
-  DLWP_PKSTEP4(-5.040322430e-04f) DLWP_PKSTEP4(2.810628898e-02f) DLWP_PKSTEP4(-1.484391242e-01f)
-  DLWP_PKSTEP4(-9.184220433e-01f) DLWP_PKSTEP4(-1.627908349e+00f)
+  DLWP_GELU_COEFFS(DLWP_PKSTEP4)
+  DLWP_PKSTEP4(-1.0f)   // exponent u Q(u) - 1
 #undef DLWP_PKSTEP4
-  f32x2 aa, ab, ac, ad;
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(aa) : "v"(pa), "v"(ta));
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ab) : "v"(pb), "v"(tb));
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ac) : "v"(pc), "v"(tc));
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ad) : "v"(pd), "v"(td));
   float m0, m1, m2, m3, m4, m5, m6, m7;
 #define DLWP_X(m, x) asm volatile("v_max_f32_e32 %0, 0, %1" : "=v"(m) : "v"(x));
   DLWP_X(m0, x0) DLWP_X(m1, x1) DLWP_X(m2, x2) DLWP_X(m3, x3)
   float e0, e1, e2, e3, e4, e5, e6, e7;
-  const float a0 = aa.x, a1 = aa.y, a2 = ab.x, a3 = ab.y, a4 = ac.x, a5 = ac.y, a6 = ad.x, a7 = ad.y;
+  const float a0 = pa.x, a1 = pa.y, a2 = pb.x, a3 = pb.y, a4 = pc.x, a5 = pc.y, a6 = pd.x, a7 = pd.y;
 #define DLWP_E(e, a) asm volatile("v_exp_f32_e32 %0, %1" : "=v"(e) : "v"(a));
   DLWP_E(e0, a0) DLWP_E(e1, a1) DLWP_E(e2, a2) DLWP_E(e3, a3) DLWP_E(e4, a4) DLWP_E(e5, a5) DLWP_E(e6, a6) DLWP_E(e7, a7)
 #undef DLWP_E
   DLWP_X(m4, x4) DLWP_X(m5, x5) DLWP_X(m6, x6) DLWP_X(m7, x7)
 #undef DLWP_X
-  f32x2 ea = {e0, e1}, eb = {e2, e3}, ec = {e4, e5}, ed = {e6, e7};
-  {
-    const f32x2 mh = {-0.5f, -0.5f};
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ea) : "v"(ea), "s"(mh));
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(eb) : "v"(eb), "s"(mh));
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ec) : "v"(ec), "s"(mh));
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ed) : "v"(ed), "s"(mh));
-  }
   float r0, r1, r2, r3, r4, r5, r6, r7;
-  const float h0 = ea.x, h1 = ea.y, h2 = eb.x, h3 = eb.y, h4 = ec.x, h5 = ec.y, h6 = ed.x, h7 = ed.y;
-#define DLWP_F(r, x, h, m) asm volatile("v_fma_f32 %0, |%1|, %2, %3" : "=v"(r) : "v"(x), "v"(h), "v"(m));
-  DLWP_F(r0, x0, h0, m0) DLWP_F(r1, x1, h1, m1) DLWP_F(r2, x2, h2, m2) DLWP_F(r3, x3, h3, m3)
-  DLWP_F(r4, x4, h4, m4) DLWP_F(r5, x5, h5, m5) DLWP_F(r6, x6, h6, m6) DLWP_F(r7, x7, h7, m7)
+#define DLWP_F(r, x, h, m) asm volatile("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(r) : "v"(x), "v"(h), "v"(m));
+  DLWP_F(r0, x0, e0, m0) DLWP_F(r1, x1, e1, m1) DLWP_F(r2, x2, e2, m2) DLWP_F(r3, x3, e3, m3)
+  DLWP_F(r4, x4, e4, m4) DLWP_F(r5, x5, e5, m5) DLWP_F(r6, x6, e6, m6) DLWP_F(r7, x7, e7, m7)
 #undef DLWP_F
   u = f32x4{r0, r1, r2, r3};
   v = f32x4{r4, r5, r6, r7};
 }
-#undef DLWP_A4
 
 // ---------------------------------------------------------------------------------------------
 // fp32 GEMM on the bf16 matrix pipe ("bf16x6")

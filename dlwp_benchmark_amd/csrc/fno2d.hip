@@ -703,7 +703,8 @@ __global__ __launch_bounds__(512) void pw_proj_bf16x6_kernel(const MlpParams p) 
 struct LayerParams {
   const float* x;     // [B][32][H][W]
   float* y;           // [B][32][H][W]
-  const float* wsp;   // [8][2][64] packed skip weights
+  const float* wsp;   // [8][2][64] packed skip weights (fp32 MFMA operands)
+  const u32x4* wsb;   // [2 halves][3 parts][64] bf16x6 A operands of the skip weights, or null
   const float* bias;  // [32]
   const float* zbuf;  // [B][H][KP][32]
   const float* t;     // T[KP][W]
@@ -716,7 +717,7 @@ struct LayerParams {
 // NO = 16-channel output tiles per wave: 2 -> one wave per row segment, 1 -> the row is split between
 // two waves (4 waves/SIMD at B*H = 2048 rows: on gfx950 VALU issue and latency hiding both improve
 // with occupancy, and the second wave's x loads hit L1/L2).
-template <int KP, bool SKIP, bool ACT, bool EMIT_Y, int NO>
+template <int KP, bool SKIP, bool ACT, bool EMIT_Y, int NO, bool SKIPB = false>
 __global__ __launch_bounds__(512) void fno_layer_kernel(const LayerParams p) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -737,12 +738,19 @@ __global__ __launch_bounds__(512) void fno_layer_kernel(const LayerParams p) {
   for (int unit = blockIdx.x * nw + wave; unit < nunit; unit += gridDim.x * nw) {
     const int row = unit / SPLIT, ot0 = (unit % SPLIT) * NO;   // first 16-channel output tile of this wave
     const int h = row % p.H, b = row / p.H;
-    float wa[8][NO];
-    if (SKIP) {
+    float wa[SKIPB ? 1 : 8][NO];
+    u32x4 wb[SKIPB ? NO : 1][3];
+    if (SKIP && !SKIPB) {
 #pragma unroll
       for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int ot = 0; ot < NO; ++ot) wa[s][ot] = p.wsp[(s * 2 + ot0 + ot) * 64 + lane];
+    }
+    if (SKIP && SKIPB) {
+#pragma unroll
+      for (int ot = 0; ot < NO; ++ot)
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) wb[ot][pp] = p.wsb[((ot0 + ot) * 3 + pp) * 64 + lane];
     }
     f32x4 bias4[NO];
 #pragma unroll
@@ -771,7 +779,7 @@ __global__ __launch_bounds__(512) void fno_layer_kernel(const LayerParams p) {
       for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[ot][q] = bias4[ot];
-      if (SKIP) {
+      if (SKIP && !SKIPB) {
         f32x4 xs[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s)
@@ -782,6 +790,28 @@ __global__ __launch_bounds__(512) void fno_layer_kernel(const LayerParams p) {
           for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int ot = 0; ot < NO; ++ot) acc[ot][q] = mfma16x16x4(wa[s][ot], xs[s][q], acc[ot][q]);
+      }
+      if (SKIP && SKIPB) {
+        // 1x1 skip convolution on the bf16 matrix pipe (bf16x6): K = 32 channels is one instruction deep;
+        // this lane supplies channels 8g..8g+7 of its 4 pixels
+        f32x4 xs[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          xs[c] = *reinterpret_cast<const f32x4*>(p.x + ((long long)b * kC + 8 * g + c) * HW + pix);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x4 bx[3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned hh, mm, ll;
+            split3_pair(xs[2 * i][q], xs[2 * i + 1][q], hh, mm, ll);
+            bx[0][i] = hh;
+            bx[1][i] = mm;
+            bx[2][i] = ll;
+          }
+#pragma unroll
+          for (int ot = 0; ot < NO; ++ot) acc[ot][q] = mfma_bf16x6(wb[ot], bx, acc[ot][q]);
+        }
       }
 #pragma unroll
       for (int s = 0; s < KP / 4; ++s) {
@@ -1112,6 +1142,8 @@ static int32_t launch_modes(const SpectralCore& sc, const float* ybuf, float* zb
   return fail(DLWP_ERR_UNSUPPORTED, "grid height %d > 256 not supported by the modes kernel", sc.H);
 }
 
+bool use_bf16x6_layer();
+
 template <bool SKIP, bool ACT, bool EMIT_Y>
 static int32_t launch_layer(const SpectralCore& sc, const LayerParams& lp, hipStream_t s) {
   // NO = 1 (row split between two waves, 4 waves/SIMD at the headline size) measured SLOWER than one
@@ -1122,13 +1154,23 @@ static int32_t launch_layer(const SpectralCore& sc, const LayerParams& lp, hipSt
   const size_t lds = EMIT_Y ? (size_t)8 * (split ? 16 : 32) * kTrStride * sizeof(float) : 0;
   const int grid = grid_rows(nrow * (split ? 2 : 1), 8);
   if (lds > 48 * 1024) {
-    DLWP_HIP_CHECK(allow_lds(fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 2>, lds));
-    DLWP_HIP_CHECK(allow_lds(fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 2>, lds));
-    DLWP_HIP_CHECK(allow_lds(fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 1>, lds));
-    DLWP_HIP_CHECK(allow_lds(fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 1>, lds));
+    DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 2, false>), lds));
+    DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 2, false>), lds));
+    DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 1, false>), lds));
+    DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 1, false>), lds));
+    DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 2, SKIP>), lds));
+    DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 2, SKIP>), lds));
+    DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 1, SKIP>), lds));
+    DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 1, SKIP>), lds));
   }
-#define DLWP_LAUNCH_LAYER(KP_, NO_) \
-  hipLaunchKernelGGL((fno_layer_kernel<KP_, SKIP, ACT, EMIT_Y, NO_>), dim3(grid), dim3(512), lds, s, lp)
+  const bool skipb = SKIP && lp.wsb != nullptr && use_bf16x6_layer();
+#define DLWP_LAUNCH_LAYER(KP_, NO_)                                                                                \
+  do {                                                                                                             \
+    if (skipb)                                                                                                     \
+      hipLaunchKernelGGL((fno_layer_kernel<KP_, SKIP, ACT, EMIT_Y, NO_, SKIP>), dim3(grid), dim3(512), lds, s, lp); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((fno_layer_kernel<KP_, SKIP, ACT, EMIT_Y, NO_, false>), dim3(grid), dim3(512), lds, s, lp); \
+  } while (0)
   if (sc.KP == 16) {
     if (split) DLWP_LAUNCH_LAYER(16, 1); else DLWP_LAUNCH_LAYER(16, 2);
   } else {
@@ -1155,7 +1197,7 @@ struct dlwp_fno2d_plan {
   DevBuf lift_w1p, lift_b1, lift_w2p, lift_b2, lift_w2b;
   DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v, proj_w1b;
   int proj_co = 0;  // outputs handled by pw_proj_small_kernel (1, 2 or 4), 0 = generic MFMA path
-  std::vector<DevBuf> wt, wsp, sbias;
+  std::vector<DevBuf> wt, wsp, sbias, wsb;
 };
 
 static void pack_w1(std::vector<float>& dst, const float* w1, int hid, int cin, int cin_steps) {
@@ -1283,7 +1325,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
     for (int i = 0; i < p->cout; ++i) b2[i] = d->proj_b2[i];
     if ((e = up(p->proj_b2, b2)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
-    p->wt.resize(p->L); p->wsp.resize(p->L); p->sbias.resize(p->L);
+    p->wt.resize(p->L); p->wsp.resize(p->L); p->sbias.resize(p->L); p->wsb.resize(p->L);
     for (int l = 0; l < p->L && e == hipSuccess; ++l) {
       std::vector<float> w((size_t)d->n_cols * d->n_rows * kC * kC * 2, 0.f);
       pack_spectral(w, d->spec_w[l], kC, kC, d->n_rows, d->n_cols, d->n_rows, 0);
@@ -1294,6 +1336,9 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
           for (int ln = 0; ln < 64; ++ln)
             ws[((size_t)st * 2 + half) * 64 + ln] = d->skip_w[l][(size_t)(16 * half + (ln & 15)) * kC + 4 * st + (ln >> 4)];
       if ((e = up(p->wsp[l], ws)) != hipSuccess) break;
+      std::vector<uint32_t> wsb;
+      pack_a_bf16x3(wsb, d->skip_w[l], kC, kC);
+      if ((e = p->wsb[l].upload(wsb.data(), wsb.size() * 4, s)) != hipSuccess) break;
       if ((e = p->sbias[l].upload(d->spec_b + (size_t)l * kC, (size_t)kC * 4, s)) != hipSuccess) break;
       if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
     }
@@ -1434,7 +1479,7 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     if (rc != DLWP_OK) return rc;
     if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::MODES));
     LayerParams lp;
-    lp.x = hin; lp.y = hout; lp.wsp = p->wsp[l].as<float>(); lp.bias = p->sbias[l].as<float>();
+    lp.x = hin; lp.y = hout; lp.wsp = p->wsp[l].as<float>(); lp.wsb = p->wsb[l].as<u32x4>(); lp.bias = p->sbias[l].as<float>();
     lp.zbuf = ws.zbuf; lp.t = p->sc.t.as<float>(); lp.tt = p->sc.tt.as<float>(); lp.ybuf = ws.ybuf;
     lp.B = B; lp.H = p->H; lp.W = p->W;
     lp.stagger = layer_stagger();
@@ -1494,6 +1539,8 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
   return DLWP_OK;
 }
 }  // namespace
+
+namespace dlwp { namespace fno { bool use_bf16x6_layer() { return use_bf16x6(); } } }
 
 extern "C" int32_t dlwp_set_fp32_mfma(int32_t on) {
   const int32_t prev = use_bf16x6() ? 0 : 1;
@@ -1690,7 +1737,7 @@ extern "C" int32_t dlwp_spectral_conv2d_f32(const dlwp_spectral_plan* plan, cons
   int32_t rc = launch_modes(sc, ybuf, zbuf, plan->wt.as<float2>(), batch, s);
   if (rc != DLWP_OK) return rc;
   LayerParams lp;
-  lp.x = x; lp.y = y; lp.wsp = nullptr; lp.bias = plan->zero_bias.as<float>(); lp.zbuf = zbuf;
+  lp.x = x; lp.y = y; lp.wsp = nullptr; lp.wsb = nullptr; lp.bias = plan->zero_bias.as<float>(); lp.zbuf = zbuf;
   lp.t = sc.t.as<float>(); lp.tt = sc.tt.as<float>(); lp.ybuf = nullptr;
   lp.B = batch; lp.H = sc.H; lp.W = sc.W;
   lp.stagger = 0;
