@@ -2,90 +2,93 @@
 //
 // Replaces reference models/fourcastnet/fourcastnet.py:87-121 -- the four full-size zero buffers, the
 // slice-assigns, eight einsums, ReLU, and softshrink of AFNO2D.forward -- with ONE pass over the
-// spectrum: for every frequency point the complex block-diagonal 2-layer MLP
+// spectrum: for every kept frequency point the complex block-diagonal 2-layer MLP
 //     o1 = relu(x W1 + b1)   (real and imaginary parts rectified separately, :96-106)
 //     o2 = o1 W2 + b2        (:108-118)
 //     y  = softshrink(o2)    (on re / im separately, :120-121)
-// is evaluated for kept modes (rows [tm-km, tm+km), cols [0, km), tm = H/2+1, km = int(tm*frac) --
-// note km along W is derived from H, :93-96) and zeros are written elsewhere, so the output is the
-// complete [B, H, W/2+1, C] spectrum irfft2 expects.  (The rfft2 / irfft2 around it currently go
-// through torch.fft = rocFFT)
+// is evaluated (kept = rows [tm-km, tm+km), cols [0, km), tm = H/2+1, km = int(tm*frac) -- km along W
+// is derived from H, :93-96) and zeros are written everywhere else, so the output is the complete
+// spectrum irfft2 expects.  The rfft2 / irfft2 around it go through torch.fft (rocFFT).
 //
-// Layout: spectrum as interleaved complex [B][H][Wf][C][2]; one thread per (point, channel); the
-// C channels of a point are consecutive threads, x and o1 are shared through LDS.
+// Layout: CHANNELS-FIRST interleaved complex [B][C][H][Wf][2] -- that is the physical layout
+// torch.fft.rfft2(x_nhwc, dim=(1,2)) produces (it transposes internally and returns a permuted view), so
+// neither side needs a copy.  One thread = one kept frequency point, all C channels, one block of `BS`
+// channels at a time in registers; lanes are consecutive along Wf (coalesced); the weights are
+// wave-uniform (scalar loads).  The thread of kept column j also zero-fills the non-kept columns
+// km + j, 2 km + j, ... of its row.
 #include "common.hpp"
 
 namespace dlwp {
 namespace afno {
 
 struct Params {
-  const float2* x;   // [P][C]
-  float2* y;         // [P][C]
+  const float2* x;   // [B][C][H][Wf]
+  float2* y;         // [B][C][H][Wf]
   const float* w1;   // [2][nb][bs][bs]
   const float* b1;   // [2][nb][bs]
   const float* w2;   // [2][nb][bs][bs]
   const float* b2;   // [2][nb][bs]
-  long long npoint;  // B*H*Wf
-  int H, Wf, C, nb, bs;
-  int row_lo, row_hi, col_hi;  // kept region
+  int B, H, Wf, C, nb;
+  int row_lo, row_hi, km;   // kept rows [row_lo, row_hi), kept cols [0, km)
   float lambd;
 };
 
 __device__ __forceinline__ float softshrink(float v, float l) { return v > l ? v - l : (v < -l ? v + l : 0.f); }
 
+template <int BS>
 __global__ __launch_bounds__(256) void afno_mix_kernel(const Params p) {
-  extern __shared__ __align__(16) float smem[];
-  float2* s_x = reinterpret_cast<float2*>(smem);  // [ppb][C]
-  float2* s_h = s_x + blockDim.x;                 // [ppb][C]
-  const int tid = threadIdx.x;
-  const int C = p.C, bs = p.bs;
-  const int ppb = blockDim.x / C;                 // points per block
-  const int pl = tid / C, c = tid % C;
-  const int blk = c / bs, o = c % bs;
-  for (long long base = (long long)blockIdx.x * ppb; base < p.npoint; base += (long long)gridDim.x * ppb) {
-    const long long pt = base + pl;
-    const bool live = pl < ppb && pt < p.npoint;
-    bool kept = false;
-    if (live) {
-      const int wf = (int)(pt % p.Wf);
-      const int h = (int)((pt / p.Wf) % p.H);
-      kept = h >= p.row_lo && h < p.row_hi && wf < p.col_hi;
-    }
-    __syncthreads();
-    if (live && kept) s_x[tid] = p.x[pt * C + c];
-    __syncthreads();
-    float2 h1 = {0.f, 0.f};
-    if (live && kept) {
-      const float* wr = p.w1 + ((long long)blk * bs) * bs + o;
-      const float* wi = wr + (long long)p.nb * bs * bs;
-      float ar = p.b1[blk * bs + o], ai = p.b1[p.nb * bs + blk * bs + o];
-      const float2* xb = s_x + pl * C + blk * bs;
-      for (int i = 0; i < bs; ++i) {
-        const float2 xv = xb[i];
-        const float r = wr[i * bs], im = wi[i * bs];
-        ar = fmaf(xv.x, r, fmaf(-xv.y, im, ar));
-        ai = fmaf(xv.y, r, fmaf(xv.x, im, ai));
-      }
-      h1 = float2{fmaxf(ar, 0.f), fmaxf(ai, 0.f)};
-      s_h[tid] = h1;
-    }
-    __syncthreads();
-    if (live) {
-      float2 out = {0.f, 0.f};
-      if (kept) {
-        const float* wr = p.w2 + ((long long)blk * bs) * bs + o;
-        const float* wi = wr + (long long)p.nb * bs * bs;
-        float ar = p.b2[blk * bs + o], ai = p.b2[p.nb * bs + blk * bs + o];
-        const float2* hb = s_h + pl * C + blk * bs;
-        for (int i = 0; i < bs; ++i) {
-          const float2 hv = hb[i];
-          const float r = wr[i * bs], im = wi[i * bs];
-          ar = fmaf(hv.x, r, fmaf(-hv.y, im, ar));
-          ai = fmaf(hv.y, r, fmaf(hv.x, im, ai));
+  const long long plane = (long long)p.H * p.Wf;
+  const long long npts = (long long)p.B * p.H * p.km;   // one thread per (b, h, kept column)
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npts;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int jcol = (int)(t % p.km);
+    const int h = (int)((t / p.km) % p.H);
+    const int b = (int)(t / ((long long)p.km * p.H));
+    const bool kept_row = h >= p.row_lo && h < p.row_hi;
+    const long long base = (long long)b * p.C * plane + (long long)h * p.Wf;
+    for (int blk = 0; blk < p.nb; ++blk) {
+      float2 out[BS];
+      if (kept_row) {
+        float2 xin[BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) xin[i] = p.x[base + (long long)(blk * BS + i) * plane + jcol];
+        const float* w1r = p.w1 + (long long)blk * BS * BS;
+        const float* w1i = w1r + (long long)p.nb * BS * BS;
+        float2 h1[BS];
+#pragma unroll
+        for (int o = 0; o < BS; ++o) {
+          float ar = p.b1[blk * BS + o], ai = p.b1[p.nb * BS + blk * BS + o];
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const float r = w1r[i * BS + o], im = w1i[i * BS + o];
+            ar = fmaf(xin[i].x, r, fmaf(-xin[i].y, im, ar));
+            ai = fmaf(xin[i].y, r, fmaf(xin[i].x, im, ai));
+          }
+          h1[o] = float2{fmaxf(ar, 0.f), fmaxf(ai, 0.f)};
         }
-        out = float2{softshrink(ar, p.lambd), softshrink(ai, p.lambd)};
+        const float* w2r = p.w2 + (long long)blk * BS * BS;
+        const float* w2i = w2r + (long long)p.nb * BS * BS;
+#pragma unroll
+        for (int o = 0; o < BS; ++o) {
+          float ar = p.b2[blk * BS + o], ai = p.b2[p.nb * BS + blk * BS + o];
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const float r = w2r[i * BS + o], im = w2i[i * BS + o];
+            ar = fmaf(h1[i].x, r, fmaf(-h1[i].y, im, ar));
+            ai = fmaf(h1[i].y, r, fmaf(h1[i].x, im, ai));
+          }
+          out[o] = float2{softshrink(ar, p.lambd), softshrink(ai, p.lambd)};
+        }
+      } else {
+#pragma unroll
+        for (int o = 0; o < BS; ++o) out[o] = float2{0.f, 0.f};
       }
-      p.y[pt * C + c] = out;
+#pragma unroll
+      for (int o = 0; o < BS; ++o) {
+        float2* yrow = p.y + base + (long long)(blk * BS + o) * plane;
+        yrow[jcol] = out[o];
+        for (int c2 = p.km + jcol; c2 < p.Wf; c2 += p.km) yrow[c2] = float2{0.f, 0.f};
+      }
     }
   }
 }
@@ -102,25 +105,30 @@ extern "C" int32_t dlwp_afno2d_mix_f32(const float* xf, float* yf, const float* 
   DLWP_REQUIRE(xf && yf && w1 && b1 && w2 && b2, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0 && H > 0 && Wf > 0 && C > 0 && num_blocks > 0 && C % num_blocks == 0, DLWP_ERR_INVALID_ARGUMENT,
                "bad shape");
-  DLWP_REQUIRE(C <= 256, DLWP_ERR_UNSUPPORTED, "hidden size %d > 256 not supported", C);
   afno::Params p;
   p.x = reinterpret_cast<const float2*>(xf);
   p.y = reinterpret_cast<float2*>(yf);
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2;
-  p.npoint = (long long)batch * H * Wf;
-  p.H = H; p.Wf = Wf; p.C = C; p.nb = num_blocks; p.bs = C / num_blocks;
+  p.B = batch; p.H = H; p.Wf = Wf; p.C = C; p.nb = num_blocks;
+  const int bs = C / num_blocks;
   const int total = H / 2 + 1;
   const int kept = (int)((double)total * (double)hard_thresholding_fraction);
+  DLWP_REQUIRE(kept >= 1, DLWP_ERR_INVALID_ARGUMENT, "hard_thresholding_fraction keeps no mode");
   p.row_lo = total - kept < 0 ? 0 : total - kept;
   p.row_hi = total + kept > H ? H : total + kept;
-  p.col_hi = kept > Wf ? Wf : kept;
+  p.km = kept > Wf ? Wf : kept;
   p.lambd = sparsity_threshold;
-  const int ppb = 256 / C;
-  const int threads = ppb * C;
-  long long blocks = (p.npoint + ppb - 1) / ppb;
+  const long long npts = (long long)batch * H * p.km;
+  long long blocks = (npts + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(afno::afno_mix_kernel, dim3((unsigned)blocks), dim3(threads), (size_t)threads * 16,
-                     reinterpret_cast<hipStream_t>(stream), p);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (bs) {
+    case 4: hipLaunchKernelGGL(afno::afno_mix_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 8: hipLaunchKernelGGL(afno::afno_mix_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 16: hipLaunchKernelGGL(afno::afno_mix_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 32: hipLaunchKernelGGL(afno::afno_mix_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    default: return fail(DLWP_ERR_UNSUPPORTED, "AFNO block size %d not supported (4, 8, 16, 32)", bs);
+  }
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }

@@ -69,6 +69,11 @@ SIGNATURES = {
                                        c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dlwp_convlstm_gates_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]),
+    "dlwp_layernorm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_float, c_void_p]),
+    "dlwp_layernorm_nhwc_to_nchw_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64, c_int32,
+                                                  c_float, c_void_p]),
+    "dlwp_afno_merge_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                      ctypes.c_int64, c_int32, c_float, c_void_p]),
     "dlwp_spectral_conv2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
 }
 

@@ -40,26 +40,35 @@ class AFNO2D(nn.Module):
         self.w2 = nn.Parameter(0.02 * torch.randn(2, num_blocks, bs, bs))
         self.b2 = nn.Parameter(0.02 * torch.randn(2, num_blocks, bs))
 
-    def forward(self, x):
-        """x [B, H, W, C] -> irfft2(mix(rfft2(x))) + x   (fourcastnet.py:78-127)"""
-        b, h, w, c = x.shape
-        xf = torch.fft.rfft2(x, dim=(1, 2), norm="ortho")
+    def filter_cf(self, x_cf):
+        """x_cf CHANNELS-FIRST [B, C, H, W] -> irfft2(mix(rfft2(x_cf))) (without the `+ bias` of :127)."""
+        h, w = x_cf.shape[-2], x_cf.shape[-1]
+        xf = torch.fft.rfft2(x_cf, norm="ortho")
         yf = ops.afno2d_mix(xf, self.w1, self.b1, self.w2, self.b2, self.num_blocks, self.sparsity_threshold,
                             self.hard_thresholding_fraction)
-        return torch.fft.irfft2(yf, s=(h, w), dim=(1, 2), norm="ortho") + x
+        return torch.fft.irfft2(yf, s=(h, w), norm="ortho")
+
+    def forward(self, x):
+        """x [B, H, W, C] -> irfft2(mix(rfft2(x))) + x   (fourcastnet.py:78-127)"""
+        x_cf = x.permute(0, 3, 1, 2).contiguous()
+        return self.filter_cf(x_cf).permute(0, 2, 3, 1) + x
 
 
 class _Block(nn.Module):
     def __init__(self, dim, mlp_ratio, num_blocks, sparsity_threshold, hard_thresholding_fraction):
         super().__init__()
-        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.norm1 = ops.HipLayerNorm(dim, eps=1e-6)
         self.filter = AFNO2D(dim, num_blocks, sparsity_threshold, hard_thresholding_fraction)
-        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.norm2 = ops.HipLayerNorm(dim, eps=1e-6)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x):
-        x = self.filter(self.norm1(x)) + x          # double skip (:186-189)
-        return self.mlp(self.norm2(x)) + x
+        """fourcastnet.py:180-193 (double skip).  LayerNorm1 writes channels-first for the FFT; the inverse
+        layout change is fused with `+ bias`, the first skip and LayerNorm2 (dlwp_afno_merge_f32)."""
+        l_cf = ops.layernorm_nhwc_to_nchw(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        f_cf = self.filter.filter_cf(l_cf)
+        s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.mlp(n) + s
 
 
 class _PatchEmbed(nn.Module):
@@ -94,7 +103,7 @@ class FourCastNet(HipBackbone):
         self.h, self.w = self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1]
         self.blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio, num_blocks, sparsity_threshold,
                                             hard_thresholding_fraction) for _ in range(depth)])
-        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)   # in the reference state dict, never applied (:283-293)
+        self.norm = ops.HipLayerNorm(embed_dim, eps=1e-6)   # in the reference state dict, never applied (:283-293)
         self.head = nn.Linear(embed_dim, self.out_chans * self.patch_size[0] * self.patch_size[1], bias=False)
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:

@@ -87,13 +87,13 @@ class _EarthSpecificBlock(nn.Module):
         self.input_resolution = tuple(input_resolution)
         self.window_size = tuple(window_size)
         self.shift_size = tuple(shift_size)
-        self.norm1 = nn.LayerNorm(dim)
+        self.norm1 = ops.HipLayerNorm(dim)
         self.padding = _pad3d(self.input_resolution, self.window_size)
         pl, lat, lon = self.input_resolution
         p = self.padding
         self.pad_resolution = (pl + p[4] + p[5], lat + p[2] + p[3], lon + p[0] + p[1])
         self.attn = _EarthAttention3D(dim, self.pad_resolution, self.window_size, num_heads)
-        self.norm2 = nn.LayerNorm(dim)
+        self.norm2 = ops.HipLayerNorm(dim)
         self.mlp = _Mlp(dim, int(dim * 4.0))
         self.roll = bool(self.shift_size[0] and self.shift_size[1] and self.shift_size[2])
         self.attention_precision = "fp32"
@@ -140,7 +140,7 @@ class _DownSample(nn.Module):
     def __init__(self, in_dim, input_resolution, output_resolution):
         super().__init__()
         self.linear = nn.Linear(in_dim * 4, in_dim * 2, bias=False)
-        self.norm = nn.LayerNorm(4 * in_dim)
+        self.norm = ops.HipLayerNorm(4 * in_dim)
         self.input_resolution, self.output_resolution = tuple(input_resolution), tuple(output_resolution)
 
     def forward(self, x):
@@ -159,7 +159,7 @@ class _UpSample(nn.Module):
         super().__init__()
         self.linear1 = nn.Linear(in_dim, out_dim * 4, bias=False)
         self.linear2 = nn.Linear(out_dim, out_dim, bias=False)
-        self.norm = nn.LayerNorm(out_dim)
+        self.norm = ops.HipLayerNorm(out_dim)
         self.input_resolution, self.output_resolution = tuple(input_resolution), tuple(output_resolution)
 
     def forward(self, x):

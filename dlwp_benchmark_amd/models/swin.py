@@ -157,7 +157,8 @@ class SwinTransformer(HipBackbone):
         self.embed_dim = embed_dim
         self.patch_size = patch_size if isinstance(patch_size, int) else int(patch_size)
         in_chans = constant_channels + (prescribed_channels + prognostic_channels) * context_size
-        norm = nn.LayerNorm if isinstance(norm_layer, str) else norm_layer   # configs pass "nn.LayerNorm"
+        # configs pass the string "nn.LayerNorm" (swintransformer.yaml:21); same parameters, HIP forward
+        norm = ops.HipLayerNorm if (isinstance(norm_layer, str) or norm_layer is nn.LayerNorm) else norm_layer
         self.patch_embed = _PatchEmbed(patch_size, in_chans, embed_dim, norm if patch_norm else None)
         res = np.array((img_height // self.patch_size, img_width // self.patch_size))
         self.layers = nn.ModuleList()

@@ -120,19 +120,74 @@ def convlstm_gates(gates: torch.Tensor, c_prev: torch.Tensor):
     return h_out, c_out
 
 
-def afno2d_mix(xf: torch.Tensor, w1, b1, w2, b2, num_blocks: int, sparsity_threshold: float,
+def afno2d_mix(xf_cf: torch.Tensor, w1, b1, w2, b2, num_blocks: int, sparsity_threshold: float,
                hard_thresholding_fraction: float) -> torch.Tensor:
-    """xf complex64 [B, H, Wf, C] (rfft2 output) -> mixed spectrum of the same shape."""
-    if not xf.is_cuda or xf.dtype != torch.complex64:
+    """xf_cf complex64 CHANNELS-FIRST [B, C, H, Wf] (rfft2 of a [B, C, H, W] tensor) -> mixed spectrum,
+    same shape and layout."""
+    if not xf_cf.is_cuda or xf_cf.dtype != torch.complex64:
         raise _lib.DlwpError("afno2d_mix needs a complex64 CUDA tensor")
-    xr = torch.view_as_real(xf.contiguous())
-    b, h, wf, c, _ = xr.shape
+    xc = xf_cf.contiguous()
+    b, c, h, wf = xc.shape
+    xr = torch.view_as_real(xc)
     yr = torch.empty_like(xr)
     lib = _lib.load()
-    with torch.cuda.device(xf.device):
+    with torch.cuda.device(xc.device):
         _lib.check(lib.dlwp_afno2d_mix_f32(xr.data_ptr(), yr.data_ptr(), w1.contiguous().data_ptr(),
                                            b1.contiguous().data_ptr(), w2.contiguous().data_ptr(),
                                            b2.contiguous().data_ptr(), b, h, wf, c, num_blocks,
                                            float(sparsity_threshold), float(hard_thresholding_fraction),
                                            _lib.stream_ptr()), "dlwp_afno2d_mix_f32")
     return torch.view_as_complex(yr)
+
+
+def layernorm_nhwc_to_nchw(x: torch.Tensor, weight, bias, eps: float) -> torch.Tensor:
+    """x [B, H, W, C] -> LayerNorm over C, returned channels-first [B, C, H, W]."""
+    _lib.require_cuda_tensor(x, "x")
+    x = x.contiguous()
+    b, h, w, c = x.shape
+    y = torch.empty(b, c, h, w, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_layernorm_nhwc_to_nchw_f32(x.data_ptr(), weight.contiguous().data_ptr(),
+                                                       bias.contiguous().data_ptr(), y.data_ptr(), b, h * w, c,
+                                                       float(eps), _lib.stream_ptr()), "dlwp_layernorm_nhwc_to_nchw_f32")
+    return y
+
+
+def afno_merge(f_nchw: torch.Tensor, l_nchw: torch.Tensor, x_nhwc: torch.Tensor, weight, bias, eps: float):
+    """(f + l) transposed to token-major + x -> (sum, LayerNorm(sum)), both [B, H, W, C]."""
+    for t, n in ((f_nchw, "f"), (l_nchw, "l"), (x_nhwc, "x")):
+        _lib.require_cuda_tensor(t, n)
+    f_nchw, l_nchw, x_nhwc = f_nchw.contiguous(), l_nchw.contiguous(), x_nhwc.contiguous()
+    b, h, w, c = x_nhwc.shape
+    s = torch.empty_like(x_nhwc)
+    n = torch.empty_like(x_nhwc)
+    lib = _lib.load()
+    with torch.cuda.device(x_nhwc.device):
+        _lib.check(lib.dlwp_afno_merge_f32(f_nchw.data_ptr(), l_nchw.data_ptr(), x_nhwc.data_ptr(),
+                                           weight.contiguous().data_ptr(), bias.contiguous().data_ptr(), s.data_ptr(),
+                                           n.data_ptr(), b, h * w, c, float(eps), _lib.stream_ptr()), "dlwp_afno_merge_f32")
+    return s, n
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """LayerNorm over the last dimension (any leading shape)."""
+    _lib.require_cuda_tensor(x, "x")
+    x = x.contiguous()
+    c = x.shape[-1]
+    rows = x.numel() // c
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_layernorm_f32(x.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                                          y.data_ptr(), rows, c, float(eps), _lib.stream_ptr()), "dlwp_layernorm_f32")
+    return y
+
+
+class HipLayerNorm(torch.nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state-dict names) whose forward runs dlwp_layernorm_f32."""
+
+    def forward(self, x):
+        if len(self.normalized_shape) != 1 or self.weight is None or self.bias is None or x.shape[-1] % 4:
+            raise _lib.DlwpError("HipLayerNorm needs a 1-D affine normalized_shape with channels % 4 == 0")
+        return layer_norm(x, self.weight, self.bias, self.eps)

@@ -195,9 +195,10 @@ int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* desc, const float* qkv_dev,
 /* ------------------------------------------------------------------------------------------
  * AFNO2D frequency-domain mixing (reference models/fourcastnet/fourcastnet.py:87-121): complex
  * block-diagonal 2-layer MLP with ReLU, mode truncation and softshrink over the rfft2 spectrum.
- * xf_dev / yf_dev: interleaved complex64 [B, H, Wf, C, 2] (Wf = W/2+1); weights in the reference
- * layouts w1,w2 [2, nb, bs, bs], b1,b2 [2, nb, bs] (device pointers).  yf is fully written
- * (zeros outside the kept modes).
+ * xf_dev / yf_dev: interleaved complex64, CHANNELS-FIRST [B, C, H, Wf, 2] (Wf = W/2+1) -- the physical
+ * layout torch.fft.rfft2(x_nhwc, dim=(1,2)) produces and irfft2 consumes without a copy; weights in the
+ * reference layouts w1,w2 [2, nb, bs, bs], b1,b2 [2, nb, bs] (device pointers), bs in {4,8,16,32}.
+ * yf is fully written (zeros outside the kept modes).
  * ------------------------------------------------------------------------------------------ */
 int32_t dlwp_afno2d_mix_f32(const float* xf_dev, float* yf_dev, const float* w1_dev, const float* b1_dev,
                             const float* w2_dev, const float* b2_dev, int32_t batch, int32_t height,
@@ -220,6 +221,28 @@ int32_t dlwp_conv3x3_cyl_f32(const float* x0_dev, int32_t c0, const float* x1_de
 int32_t dlwp_convlstm_gates_f32(const float* gates_dev, const float* c_prev_dev, float* h_out_dev,
                                 float* c_out_dev, int32_t batch, int32_t hidden, int32_t height,
                                 int32_t width, void* stream);
+
+/* LayerNorm over the last dimension of a token-major tensor x_dev [rows, channels] (channels % 4 == 0,
+ * <= 2048): y = (x - mean) * rsqrt(var + eps) * gamma + beta, biased variance (torch.nn.LayerNorm).
+ * Reference call sites: models/fourcastnet/fourcastnet.py:180-193, models/swintransformer/
+ * swin_transformer.py:213,262,304,440,664, models/panguweather/panguweather.py:73,127,281,321. */
+int32_t dlwp_layernorm_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
+                           int64_t rows, int32_t channels, float eps, void* stream);
+
+/* FourCastNet block glue fused with the layout change the FFT needs (models/fourcastnet/fourcastnet.py
+ * :180-193 around AFNO2D :78-127).  x is token-major [B, tokens, C] ("NHWC"), y / f / l channel-major
+ * [B, C, tokens] ("NCHW"); C % 4 == 0, C <= 256.
+ *   dlwp_layernorm_nhwc_to_nchw_f32: y = LayerNorm1(x), written channel-major (:182 norm1 + the transpose
+ *       torch.fft.rfft2(dim=(1,2)) would otherwise do with a strided copy)
+ *   dlwp_afno_merge_f32: sum = f + l + x  (irfft2 output + AFNO2D "+ bias" :127 + first skip :187),
+ *       norm = LayerNorm2(sum) (:191); both token-major. */
+int32_t dlwp_layernorm_nhwc_to_nchw_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                                        float* y_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
+                                        void* stream);
+int32_t dlwp_afno_merge_f32(const float* f_nchw_dev, const float* l_nchw_dev, const float* x_nhwc_dev,
+                            const float* gamma_dev, const float* beta_dev, float* sum_nhwc_dev,
+                            float* norm_nhwc_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import json
 import pytest
 import torch
 
-from helpers import load_golden, per_step_rel_l2
+from helpers import load_golden, per_step_rel_l2, rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -79,3 +79,15 @@ def test_bf16_attention_stays_close_to_reference(tag):
     print(tag, "bf16 attention per-step rel L2:", ["%.2e" % e for e in errs])
     assert max(errs) <= 5e-3, errs
     assert max(errs) > 1e-7, "bf16 path suspiciously exact: is it running?"
+
+
+@pytest.mark.parametrize("rows,c", [(37, 16), (1000, 64), (513, 96), (64, 384), (10, 768), (3, 2048)])
+def test_layernorm_kernel(rows, c):
+    from dlwp_benchmark_amd import ops
+
+    torch.manual_seed(rows + c)
+    x = torch.randn(rows, c) * 3 + 1.5
+    w, b = torch.randn(c), torch.randn(c)
+    want = torch.nn.functional.layer_norm(x.double(), (c,), w.double(), b.double(), 1e-6)
+    got = ops.layer_norm(x.cuda(), w.cuda(), b.cuda(), 1e-6)
+    assert rel_l2(got, want) < 5e-7
