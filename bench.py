@@ -131,13 +131,21 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # DLWP_BENCH_BACKEND=gloo + DLWP_BENCH_ONE_GPU=1: rehearse the multi-rank control flow on a
+    # one-GPU box (every rank on cuda:0, gloo for the collectives); the real run uses nccl (= RCCL).
+    backend = os.environ.get("DLWP_BENCH_BACKEND", "nccl")
+    if os.environ.get("DLWP_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dlwp_benchmark_amd.sharding import ShardedRollout
     from dlwp_benchmark_amd.synthetic import navier_stokes
@@ -164,7 +172,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3

@@ -64,9 +64,13 @@ class ShardedRollout:
 
             bounds = chunk_bounds(k, self.chunks)
             works, parts = [], []
+            # a CPU-only backend (gloo rehearsal on a one-GPU box) cannot move device tensors: stage on the host
+            host = local.is_cuda and dist.get_backend(self.group) != "nccl"
             for (a, e) in bounds:
                 m.rollout_into(local, constants, prescribed, prognostic, a, e)
                 send = local[:, a:e].contiguous()
+                if host:
+                    send = send.cpu()
                 recv = torch.empty((self.world * b,) + tuple(send.shape[1:]), device=send.device, dtype=send.dtype)
                 works.append(dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True))
                 parts.append((send, recv))
@@ -74,5 +78,5 @@ class ShardedRollout:
             ov = out.view(self.world, b, k, cg, h, w)
             for (a, e), wk, (_, recv) in zip(bounds, works, parts):
                 wk.wait()
-                ov[:, :, a:e].copy_(recv.view(self.world, b, e - a, cg, h, w))
+                ov[:, :, a:e].copy_(recv.view(self.world, b, e - a, cg, h, w), non_blocking=True)
             return out
