@@ -94,7 +94,7 @@ __device__ __forceinline__ int pack_info(const Coord& c) {
 //       (rows 4g..4g+3 of the accumulator) are consecutive along longitude: ONE bias index per 4 scores.
 // All score arithmetic is in the log2 domain (q scale, bias table and mask are pre-multiplied by
 // log2 e) so the softmax exponentials are bare v_exp_f32.
-template <int DT, int DB, int SUB, bool BF16, bool LON4>
+template <int DT, int DB, int SUB, bool BF16, bool LON4, bool MASK>
 __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const float* __restrict__ qkv,
                                                           const float* __restrict__ qkv_bias,
                                                           const float* __restrict__ table,
@@ -127,6 +127,12 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
   unsigned short* s_vb = s_kb + KT * LDKB;                          // bf16: [16*DB][LDVB]  (V transposed)
   constexpr int KV_FLOATS = BF16 ? (KT * LDKB + 16 * DB * LDVB + 1) / 2 : KT * (LDK + LDV);
   int* s_info = reinterpret_cast<int*>(s_kv + ((KV_FLOATS + 3) & ~3));  // [KT] packed key coords, -1 beyond N
+  constexpr int EPI_FLOATS = 64 * SUB * (16 * DB + 1);
+  constexpr int TILE_FLOATS = ((KV_FLOATS + 3) & ~3) + KT;
+  // window token map, computed once per workgroup: source token (or -1 = zero-padded) and packed
+  // coordinates / region of every in-window position (token_coord is ~10 integer divisions)
+  int* s_msrc = reinterpret_cast<int*>(s_kv + (((TILE_FLOATS > EPI_FLOATS ? TILE_FLOATS : EPI_FLOATS) + 3) & ~3));  // [N]
+  int* s_minfo = s_msrc + ((N + 3) & ~3);                                                                        // [N]
 
   {
     const int type = ipl * D.nlat + ilat;
@@ -134,6 +140,13 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
     const float* col = table + (D.bias_mode ? (long long)type * D.heads : 0) + head;
     for (int i = tid; i < D.table_rows; i += 256) s_tab[i] = col[i * stride] * LOG2E;
   }
+
+  for (int n = tid; n < N; n += 256) {
+    const Coord c = token_coord(D, ipl, ilat, ilon, n);
+    s_msrc[n] = (int)c.src;
+    s_minfo[n] = pack_info(c);
+  }
+  __syncthreads();
 
   const float* qkv_b = qkv + (long long)b * L * 3 * C;
   const int q_base = blockIdx.x * (64 * SUB) + wave * (16 * SUB);
@@ -144,15 +157,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
 #pragma unroll
   for (int sub = 0; sub < SUB; ++sub) {
     const int qn = q_base + 16 * sub + j;
-    Coord c;
-    c.src = -1;
-    qinfo[sub] = 0;
     const bool live = qn < N;
-    if (live) {
-      c = token_coord(D, ipl, ilat, ilon, qn);
-      qinfo[sub] = pack_info(c);
-    }
-    const float* src = (live && c.src >= 0) ? qkv_b + c.src * 3 * C + head * d : qkv_bias + head * d;
+    const int qsrc = live ? s_msrc[qn] : -1;
+    qinfo[sub] = live ? s_minfo[qn] : 0;
+    const float* src = (live && qsrc >= 0) ? qkv_b + (long long)qsrc * 3 * C + head * d : qkv_bias + head * d;
     if constexpr (!BF16) {
 #pragma unroll
       for (int s = 0; s < DT; ++s) qreg[sub][s] = live ? src[4 * s + g] * qscale : 0.f;
@@ -181,56 +189,81 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
   const float mask_val = -100.0f * LOG2E;
 
   const int ntile = (N + KT - 1) / KT;
-  for (int kt = 0; kt < ntile; ++kt) {
-    __syncthreads();
-    // ---- stage keys kt*32 .. +31: K, V (converted / transposed for the bf16 path) and key info
-    if constexpr (!BF16) {
-      for (int i = tid; i < KT * 4 * DT; i += 256) {
+  // ---- K/V staging split in two (global -> registers early, registers -> LDS late) so the global
+  // latency of tile kt+1 hides behind the MFMA / softmax work of tile kt
+  constexpr int EP = 16 * DK;                                         // bf16: element pairs per key row
+  constexpr int NI = BF16 ? (KT * EP + 255) / 256 : (KT * 4 * DT + 255) / 256;   // staging items per thread
+  float pk0[NI], pk1[BF16 ? NI : 1], pv0[NI], pv1[BF16 ? NI : 1];
+  int pinfo[NI];
+  auto stage_load = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = tid + it * 256;
+      if constexpr (!BF16) {
         const int key = i / (4 * DT), e = i % (4 * DT);
         const int kn = kt * KT + key;
-        float kv = 0.f, vv = 0.f;
-        if (kn < N) {
-          const Coord c = token_coord(D, ipl, ilat, ilon, kn);
-          if (e == 0) s_info[key] = pack_info(c);
-          const float* src = c.src >= 0 ? qkv_b + c.src * 3 * C + head * d : qkv_bias + head * d;
-          kv = src[C + e];
-          vv = src[2 * C + e];
-        } else if (e == 0) {
-          s_info[key] = -1;
+        pk0[it] = 0.f; pv0[it] = 0.f; pinfo[it] = -1;
+        if (i < KT * 4 * DT && kn < N) {
+          const int ksrc = s_msrc[kn];
+          pinfo[it] = s_minfo[kn];
+          const float* src = ksrc >= 0 ? qkv_b + (long long)ksrc * 3 * C + head * d : qkv_bias + head * d;
+          pk0[it] = src[C + e];
+          pv0[it] = src[2 * C + e];
         }
-        s_k[key * LDK + e] = kv;
-        s_v[key * LDV + e] = vv;
-      }
-      if (16 * DB > 4 * DT) {
-        for (int i = tid; i < KT * (16 * DB - 4 * DT); i += 256) {
-          const int key = i / (16 * DB - 4 * DT), e = 4 * DT + i % (16 * DB - 4 * DT);
-          s_v[key * LDV + e] = 0.f;
-        }
-      }
-    } else {
-      constexpr int EP = 16 * DK;  // element pairs per key row (head dims padded to 32*DK)
-      for (int i = tid; i < KT * EP; i += 256) {
+      } else {
         const int key = i / EP, e = 2 * (i % EP);
         const int kn = kt * KT + key;
-        float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
-        if (kn < N) {
-          const Coord c = token_coord(D, ipl, ilat, ilon, kn);
-          if (e == 0) s_info[key] = pack_info(c);
-          const float* src = c.src >= 0 ? qkv_b + c.src * 3 * C + head * d : qkv_bias + head * d;
-          if (e < d) { k0 = src[C + e]; v0 = src[2 * C + e]; }
-          if (e + 1 < d) { k1 = src[C + e + 1]; v1 = src[2 * C + e + 1]; }
-        } else if (e == 0) {
-          s_info[key] = -1;
-        }
-        *reinterpret_cast<unsigned*>(s_kb + key * LDKB + e) = cvt_pk_bf16(k0, k1);
-        if (e < 16 * DB) {
-          const unsigned vp = cvt_pk_bf16(v0, v1);
-          s_vb[e * LDVB + key] = (unsigned short)(vp & 0xFFFFu);
-          s_vb[(e + 1) * LDVB + key] = (unsigned short)(vp >> 16);
+        pk0[it] = 0.f; pk1[it] = 0.f; pv0[it] = 0.f; pv1[it] = 0.f; pinfo[it] = -1;
+        if (i < KT * EP && kn < N) {
+          const int ksrc = s_msrc[kn];
+          pinfo[it] = s_minfo[kn];
+          const float* src = ksrc >= 0 ? qkv_b + (long long)ksrc * 3 * C + head * d : qkv_bias + head * d;
+          if (e < d) { pk0[it] = src[C + e]; pv0[it] = src[2 * C + e]; }
+          if (e + 1 < d) { pk1[it] = src[C + e + 1]; pv1[it] = src[2 * C + e + 1]; }
         }
       }
     }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = tid + it * 256;
+      if constexpr (!BF16) {
+        if (i < KT * 4 * DT) {
+          const int key = i / (4 * DT), e = i % (4 * DT);
+          if (e == 0) s_info[key] = pinfo[it];
+          s_k[key * LDK + e] = pk0[it];
+          s_v[key * LDV + e] = pv0[it];
+        }
+      } else {
+        if (i < KT * EP) {
+          const int key = i / EP, e = 2 * (i % EP);
+          if (e == 0) s_info[key] = pinfo[it];
+          *reinterpret_cast<unsigned*>(s_kb + key * LDKB + e) = cvt_pk_bf16(pk0[it], pk1[it]);
+          if (e < 16 * DB) {
+            const unsigned vp = cvt_pk_bf16(pv0[it], pv1[it]);
+            s_vb[e * LDVB + key] = (unsigned short)(vp & 0xFFFFu);
+            s_vb[(e + 1) * LDVB + key] = (unsigned short)(vp >> 16);
+          }
+        }
+      }
+    }
+  };
+  if constexpr (!BF16) {
+    if (16 * DB > 4 * DT) {   // pad columns of V (head_dim not a multiple of 16): zero once
+      for (int i = tid; i < KT * (16 * DB - 4 * DT); i += 256) {
+        const int key = i / (16 * DB - 4 * DT), e = 4 * DT + i % (16 * DB - 4 * DT);
+        s_v[key * LDV + e] = 0.f;
+      }
+    }
+  }
+  stage_load(0);
+  for (int kt = 0; kt < ntile; ++kt) {
+    const bool tail = (kt == ntile - 1) && (N % KT != 0);
+    __syncthreads();          // everyone is done reading the previous tile
+    stage_write();
     __syncthreads();
+    if (kt + 1 < ntile) stage_load(kt + 1);
 
 #pragma unroll
     for (int sub = 0; sub < SUB; ++sub) {
@@ -283,8 +316,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
             if (ki < 0) idx = 0;
           }
           float v = sc[kb][r] + s_tab[idx];
-          if (D.use_mask && ((ki >> 20) & 0x1F) != qreg_id) v += mask_val;
-          v = ki < 0 ? -1e30f : v;
+          if (MASK) v += (((ki >> 20) & 0x1F) != qreg_id) ? mask_val : 0.f;
+          if (tail) v = ki < 0 ? -1e30f : v;   // only the last tile can hold keys beyond N
           sc[kb][r] = v;
           mx = fmaxf(mx, v);
         }
@@ -373,12 +406,11 @@ static int32_t launch_wattn_k(const Desc& D, const float* qkv, const float* qkv_
   constexpr int KT = 32, LDK = 4 * DT + 2, LDV = 16 * DB + 4, DK = (4 * DT + 31) / 32, LDKB = 32 * DK + 8, LDVB = KT + 8;
   constexpr int KV_FLOATS = BF16 ? (KT * LDKB + 16 * DB * LDVB + 1) / 2 : KT * (LDK + LDV);
   const size_t tab = (size_t)((D.table_rows + 3) & ~3);
-  size_t lds = (tab + ((KV_FLOATS + 3) & ~3) + KT) * 4;
-  const size_t epi = (tab + (size_t)64 * SUB * (16 * DB + 1)) * 4;
-  if (epi > lds) lds = epi;
+  const size_t tile_f = (size_t)((KV_FLOATS + 3) & ~3) + KT, epi_f = (size_t)64 * SUB * (16 * DB + 1);
+  const size_t lds = (tab + (((tile_f > epi_f ? tile_f : epi_f) + 3) & ~(size_t)3) + 2 * (size_t)((D.N + 3) & ~3)) * 4;
   DLWP_REQUIRE(lds <= 160 * 1024, DLWP_ERR_UNSUPPORTED, "window attention needs %zu bytes of LDS (bias table too large)", lds);
   const dim3 grid((D.N + 64 * SUB - 1) / (64 * SUB), D.heads, batch * nwin);
-  auto kern = window_attn_kernel<DT, DB, SUB, BF16, LON4>;
+  auto kern = D.use_mask ? window_attn_kernel<DT, DB, SUB, BF16, LON4, true> : window_attn_kernel<DT, DB, SUB, BF16, LON4, false>;
   if (lds > 48 * 1024)
     DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, D, qkv, qkv_bias, table, out, L);
@@ -389,17 +421,23 @@ static int32_t launch_wattn_k(const Desc& D, const float* qkv, const float* qkv_
 template <int DT, int DB>
 static int32_t launch_wattn(const Desc& D, const float* qkv, const float* qkv_bias, const float* table, float* out,
                             int batch, long long L, hipStream_t s, bool bf16) {
-  const bool big = D.N >= 512;
+  // queries per workgroup = 64 * SUB.  Large windows: 128; small windows: the whole window in one
+  // workgroup when it fits 256 queries, so the bias column / token map staging is paid once per
+  // (window, head) instead of once per 64 queries (Pangu: N = 144 -> SUB = 3)
+  const int sub = D.N >= 512 ? 2 : (D.N <= 64 ? 1 : (D.N <= 128 ? 2 : (D.N <= 192 ? 3 : 4)));
   const bool lon4 = (D.wlon % 4) == 0;
-#define DLWP_WA(SUB_, BF_, L4_) return launch_wattn_k<DT, DB, SUB_, BF_, L4_>(D, qkv, qkv_bias, table, out, batch, L, s)
-  if (bf16) {
-    if (big) { if (lon4) DLWP_WA(2, true, true); else DLWP_WA(2, true, false); }
-    else { if (lon4) DLWP_WA(1, true, true); else DLWP_WA(1, true, false); }
-  } else {
-    if (big) { if (lon4) DLWP_WA(2, false, true); else DLWP_WA(2, false, false); }
-    else { if (lon4) DLWP_WA(1, false, true); else DLWP_WA(1, false, false); }
+#define DLWP_WA2(SUB_, BF_) \
+  do { if (lon4) return launch_wattn_k<DT, DB, SUB_, BF_, true>(D, qkv, qkv_bias, table, out, batch, L, s); \
+       else return launch_wattn_k<DT, DB, SUB_, BF_, false>(D, qkv, qkv_bias, table, out, batch, L, s); } while (0)
+#define DLWP_WA(SUB_) do { if (bf16) DLWP_WA2(SUB_, true); else DLWP_WA2(SUB_, false); } while (0)
+  switch (sub) {
+    case 1: DLWP_WA(1);
+    case 2: DLWP_WA(2);
+    case 3: DLWP_WA(3);
+    default: DLWP_WA(4);
   }
 #undef DLWP_WA
+#undef DLWP_WA2
 }
 
 static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias, const float* table,
@@ -442,15 +480,15 @@ static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, cons
   }
   const bool padded = (D.ppl != D.pl) || (D.plat != D.lat) || (D.plon != D.lon);
   DLWP_REQUIRE(!padded || qkv_bias, DLWP_ERR_INVALID_ARGUMENT, "padded windows need the qkv bias (zero-padded tokens carry it)");
-  DLWP_REQUIRE(D.d % 4 == 0 && D.d >= 4 && D.d <= 64, DLWP_ERR_UNSUPPORTED, "head_dim %d must be a multiple of 4 in [4,64]", D.d);
+  DLWP_REQUIRE(D.d == 8 || D.d == 16 || D.d == 24 || D.d == 32 || D.d == 48 || D.d == 64, DLWP_ERR_UNSUPPORTED,
+               "head_dim %d: kernels are instantiated for 8, 16, 24, 32, 48, 64", D.d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long L = (long long)D.pl * D.lat * D.lon;
   const float* qb = qkv_bias ? qkv_bias : qkv;  // never dereferenced when nothing is padded
   switch (D.d / 4) {
 #define DLWP_CASE(DT_) \
   case DT_: return launch_wattn<DT_, (4 * DT_ + 15) / 16>(D, qkv, qb, table, out, batch, L, s, bf16);
-    DLWP_CASE(1) DLWP_CASE(2) DLWP_CASE(3) DLWP_CASE(4) DLWP_CASE(5) DLWP_CASE(6) DLWP_CASE(7) DLWP_CASE(8)
-    DLWP_CASE(9) DLWP_CASE(10) DLWP_CASE(11) DLWP_CASE(12) DLWP_CASE(13) DLWP_CASE(14) DLWP_CASE(15) DLWP_CASE(16)
+    DLWP_CASE(2) DLWP_CASE(4) DLWP_CASE(6) DLWP_CASE(8) DLWP_CASE(12) DLWP_CASE(16)
 #undef DLWP_CASE
     default: break;
   }
