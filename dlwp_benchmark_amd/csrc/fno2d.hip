@@ -1379,7 +1379,7 @@ bool use_bf16x6() {
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
 struct KernelTimer {
-  enum { LIFT = 0, MODES = 1, LAYER = 2, PROJ = 3, NCLASS = 4 };
+  enum { LIFT = 0, MODES = 1, LAYER = 2, PROJ = 3, EMPTY = 4, NCLASS = 5 };
   std::vector<hipEvent_t> ev[NCLASS];  // start/stop pairs
   hipStream_t s = nullptr;
   hipError_t begin(int cls) {
@@ -1438,6 +1438,10 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
                  long long out_bstride, const float* resid, long long resid_bstride, hipStream_t s,
                  KernelTimer* timer = nullptr) {
   const int nrow = B * p->H;
+  if (timer) {  // calibration: an empty bracket measures what the event pair itself adds
+    DLWP_HIP_CHECK(timer->begin(KernelTimer::EMPTY));
+    DLWP_HIP_CHECK(timer->end(KernelTimer::EMPTY));
+  }
   // lifting (+ W-direction DFT of its output)
   {
     MlpParams mp;

@@ -119,9 +119,9 @@ int32_t dlwp_fno2d_rollout_range_f32(const dlwp_fno2d_plan* plan, const float* c
 
 /* Same rollout with every kernel launch bracketed by a pair of HIP events on `stream`
  * (measurement aid for bench.py's roofline leg; synchronises the stream before returning).
- * Kernel classes: 0 lifting MLP (pw_mlp2_kernel<..,EMIT_Y>), 1 fno_modes_kernel,
- * 2 fno_layer_kernel, 3 projection MLP (pw_mlp2_kernel<..,RESID>).
- * class_ms[4]: summed event-to-event milliseconds, class_launches[4]: launches per class. */
+ * Kernel classes: 0 lifting MLP, 1 fno_modes_kernel, 2 fno_layer_kernel, 3 projection MLP,
+ * 4 an EMPTY bracket per step (what the event pair itself adds; subtract its average from the others).
+ * class_ms[5]: summed event-to-event milliseconds, class_launches[5]: brackets per class. */
 int32_t dlwp_fno2d_rollout_profiled_f32(const dlwp_fno2d_plan* plan, const float* constants_dev,
                                         int32_t n_const, const float* prescribed_dev,
                                         int32_t n_presc, const float* prognostic_dev,
