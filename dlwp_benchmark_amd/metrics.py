@@ -1,0 +1,70 @@
+"""On-device evaluation metrics.
+
+`RolloutMetrics` reduces a rollout [B, K, C, H, W] and its targets to latitude-weighted RMSE (and ACC
+when a climatology is given) per lead time and variable -- the quantities reference
+scripts/evaluate.py:786-821 computes with xarray after copying every trajectory to the host, with the
+per-variable de-normalisation of evaluate.py:281-296 folded in as a scale (the means cancel).
+Multi-GPU: the [4, K, C] double sums are all-reduced (a few hundred bytes) instead of gathering
+trajectories.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+
+def latitude_weights(lats_deg: torch.Tensor) -> torch.Tensor:
+    """cos(lat_j) / mean_j cos(lat_j)  (evaluate.py:788-790, Eq. (2) of arXiv:2002.00469)."""
+    w = torch.cos(torch.deg2rad(lats_deg.double()))
+    return (w / w.mean()).float()
+
+
+class RolloutMetrics:
+    def __init__(self, lats_deg: torch.Tensor, std: Optional[torch.Tensor] = None,
+                 climatology: Optional[torch.Tensor] = None, group=None):
+        self.latw = latitude_weights(lats_deg)
+        self.std = std.float() if std is not None else None
+        self.clim = climatology.float() if climatology is not None else None
+        self.group = group
+
+    def sums(self, out: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """double [4, K, C] sums of this rank's samples (see dlwp_weighted_error_sums_f32)."""
+        _lib.require_cuda_tensor(out, "out")
+        _lib.require_cuda_tensor(target, "target")
+        out, target = out.contiguous(), target.contiguous()
+        b, k, c, h, w = out.shape
+        if target.shape != out.shape:
+            raise _lib.DlwpError(f"target shape {tuple(target.shape)} != output shape {tuple(out.shape)}")
+        dev = out.device
+        latw = self.latw.to(dev)
+        std = self.std.to(dev).contiguous() if self.std is not None else None
+        clim = self.clim.to(dev).contiguous() if self.clim is not None else None
+        sums = torch.empty(4, k, c, dtype=torch.float64, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.dlwp_weighted_error_sums_f32(
+                out.data_ptr(), target.data_ptr(), clim.data_ptr() if clim is not None else None, latw.data_ptr(),
+                std.data_ptr() if std is not None else None, sums.data_ptr(), b, k, c, h, w, _lib.stream_ptr()),
+                "dlwp_weighted_error_sums_f32")
+        return sums
+
+    def __call__(self, out: torch.Tensor, target: torch.Tensor, world_size: int = 1):
+        """Returns {"rmse": [K, C], "acc": [K, C] or None} over ALL ranks' samples."""
+        s = self.sums(out, target)
+        n = torch.tensor([float(out.shape[0])], dtype=torch.float64, device=out.device)
+        if world_size > 1:
+            import torch.distributed as dist
+
+            host = dist.get_backend(self.group) != "nccl"
+            buf = torch.cat([s.flatten(), n])
+            if host:
+                buf = buf.cpu()
+            dist.all_reduce(buf, group=self.group)
+            buf = buf.to(out.device)
+            s, n = buf[:-1].view_as(s), buf[-1:]
+        count = n * out.shape[-2] * out.shape[-1]
+        rmse = torch.sqrt(s[0] / count)
+        acc = s[1] / torch.sqrt(s[2] * s[3]) if self.clim is not None else None
+        return {"rmse": rmse, "acc": acc}

@@ -244,6 +244,17 @@ int32_t dlwp_afno_merge_f32(const float* f_nchw_dev, const float* l_nchw_dev, co
                             float* norm_nhwc_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
                             void* stream);
 
+/* On-device evaluation sums (reference scripts/evaluate.py:786-821 `compute_metrics` + the
+ * de-normalisation of :281-296): out_dev, target_dev [B, K, C, H, W]; climatology_dev [K, C, H, W] or NULL;
+ * lat_weights_dev [H] (cos(lat)/mean(cos(lat))); scale_dev [C] (per-variable std) or NULL.
+ * sums_dev: double [4, K, C], zeroed by the call:  0: sum w (s (out-tar))^2,  1: sum w s^2 (out-clim)(tar-clim),
+ * 2: sum w (s (out-clim))^2,  3: sum w (s (tar-clim))^2  (1-3 only with a climatology).
+ * RMSE[k,c] = sqrt(sums[0] / (B_total H W)),  ACC = sums[1] / sqrt(sums[2] sums[3]). */
+int32_t dlwp_weighted_error_sums_f32(const float* out_dev, const float* target_dev, const float* climatology_dev,
+                                     const float* lat_weights_dev, const float* scale_dev, double* sums_dev,
+                                     int32_t batch, int32_t steps, int32_t channels, int32_t height, int32_t width,
+                                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

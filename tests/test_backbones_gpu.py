@@ -91,3 +91,43 @@ def test_layernorm_kernel(rows, c):
     want = torch.nn.functional.layer_norm(x.double(), (c,), w.double(), b.double(), 1e-6)
     got = ops.layer_norm(x.cuda(), w.cuda(), b.cuda(), 1e-6)
     assert rel_l2(got, want) < 5e-7
+
+
+def test_on_device_metrics_match_restated_formulas():
+    import numpy as np
+
+    from dlwp_benchmark_amd.metrics import RolloutMetrics
+    from oracle.restate.metrics import lat_weighted_metrics
+
+    g = torch.Generator().manual_seed(5)
+    n, k, c, h, w = 6, 5, 3, 32, 64
+    out = torch.randn(n, k, c, h, w, generator=g)
+    tar = out + 0.1 * torch.randn(n, k, c, h, w, generator=g)
+    clim = 0.3 * torch.randn(k, c, h, w, generator=g)
+    lats = torch.linspace(-87.1875, 87.1875, h)
+    std = torch.tensor([2.0, 0.5, 10.0])
+    mean = torch.tensor([1.0, -3.0, 250.0])
+    want_rmse, want_acc = lat_weighted_metrics(out.numpy(), tar.numpy(), lats.numpy(), std.numpy(), mean.numpy(), clim.numpy())
+    m = RolloutMetrics(lats, std=std, climatology=clim)
+    got = m(out.cuda(), tar.cuda())
+    np.testing.assert_allclose(got["rmse"].cpu().numpy(), want_rmse, rtol=2e-6)
+    np.testing.assert_allclose(got["acc"].cpu().numpy(), want_acc, rtol=2e-6, atol=1e-7)
+
+
+def test_device_stager_delivers_identical_batches():
+    from dlwp_benchmark_amd.staging import DeviceStager
+
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for i in range(4):
+        cons = torch.randn(2, 1, 4, 8, 16, generator=g)
+        presc = torch.full((2, 5, 1, 8, 16), float("nan")) if i % 2 else torch.randn(2, 5, 1, 8, 16, generator=g)
+        prog = torch.randn(2, 5, 3, 8, 16, generator=g)
+        batches.append((cons, presc, prog, prog[:, 1:].clone()))
+    got = list(DeviceStager(batches, "cuda:0"))
+    assert len(got) == 4
+    for i, (c, p, g_, t) in enumerate(got):
+        assert torch.equal(c.cpu(), batches[i][0]) and torch.equal(g_.cpu(), batches[i][2]) and torch.equal(t.cpu(), batches[i][3])
+        assert (p is None) == bool(i % 2)
+        if p is not None:
+            assert torch.equal(p.cpu(), batches[i][1])
