@@ -34,6 +34,10 @@ struct Params {
   const float* bias;         // [Cout] or null
   float* y;                  // [B][Cout][H][W]
   int B, H, W, Cout, act;
+  // HEALPix topology (null = cylinder): [12][(H+2)*(W+2)] entries (a, b) for the halo ring of every face;
+  // a, b = face*H*W + pixel inside the same sample, b < 0 -> single source, else the mean of both
+  // (the synthesised corners of the equatorial faces, reference utils/healpix.py:316-368).
+  const int2* hpx;
 };
 
 __global__ __launch_bounds__(256) void conv3x3_cyl_kernel(const Params p) {
@@ -61,7 +65,25 @@ __global__ __launch_bounds__(256) void conv3x3_cyl_kernel(const Params p) {
         const int ih = h0 + r - 1;
         int iw = w0 + cc - 1;
         float v = 0.f;
-        if (c < cin && ih >= 0 && ih < p.H && iw >= -1 && iw <= p.W) {
+        if (p.hpx) {
+          if (c < cin && ih >= -1 && ih <= p.H && iw >= -1 && iw <= p.W) {
+            const bool seg0 = c < p.c0;
+            const float* base = seg0 ? p.x0 : p.x1;
+            const int cs = seg0 ? p.c0 : p.c1, cl = seg0 ? c : c - p.c0;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+              v = base[((long long)b * cs + cl) * HW + (long long)ih * p.W + iw];
+            } else {
+              const int face = b % 12, s0 = b - face;
+              const int2 e = p.hpx[(long long)face * (p.H + 2) * (p.W + 2) + (ih + 1) * (p.W + 2) + (iw + 1)];
+              const int fa = e.x / (int)HW;
+              v = base[((long long)(s0 + fa) * cs + cl) * HW + (e.x - fa * (int)HW)];
+              if (e.y >= 0) {
+                const int fb = e.y / (int)HW;
+                v = 0.5f * v + 0.5f * base[((long long)(s0 + fb) * cs + cl) * HW + (e.y - fb * (int)HW)];
+              }
+            }
+          }
+        } else if (c < cin && ih >= 0 && ih < p.H && iw >= -1 && iw <= p.W) {
           iw = iw < 0 ? iw + p.W : (iw >= p.W ? iw - p.W : iw);   // circular longitude
           const float* src = c < p.c0 ? p.x0 + ((long long)b * p.c0 + c) * HW
                                       : p.x1 + ((long long)b * p.c1 + (c - p.c0)) * HW;
@@ -102,6 +124,29 @@ __global__ __launch_bounds__(256) void conv3x3_cyl_kernel(const Params p) {
   }
 }
 
+// HEALPixPadding(p) as a table-driven gather (reference utils/healpix.py:165-368): y [(B*12)][C][H+2p][W+2p],
+// table [12][(H+2p)*(W+2p)] of (a, b) sources as above (interior cells map to themselves).
+__global__ __launch_bounds__(256) void healpix_pad_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const int2* __restrict__ table, int C, int HW, int PHW,
+                                                          long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cell = (int)(i % PHW);
+    const long long fc = i / PHW;
+    const int c = (int)(fc % C);
+    const long long n = fc / C;
+    const int face = (int)(n % 12);
+    const long long s0 = n - face;
+    const int2 e = table[(long long)face * PHW + cell];
+    const int fa = e.x / HW;
+    float v = x[((s0 + fa) * C + c) * HW + (e.x - fa * HW)];
+    if (e.y >= 0) {
+      const int fb = e.y / HW;
+      v = 0.5f * v + 0.5f * x[((s0 + fb) * C + c) * HW + (e.y - fb * HW)];
+    }
+    y[i] = v;
+  }
+}
+
 // ConvLSTM cell gate math (convlstm.py:96-109): gates [B][4*hid][H][W] = (netin, igate, fgate, ogate)
 __global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __restrict__ gates,
                                                              const float* __restrict__ c_prev, float* __restrict__ h_out,
@@ -138,9 +183,43 @@ extern "C" int32_t dlwp_conv3x3_cyl_f32(const float* x0, int32_t c0, const float
   DLWP_REQUIRE(act >= 0 && act <= 4, DLWP_ERR_INVALID_ARGUMENT, "unknown activation %d", act);
   conv::Params p;
   p.x0 = x0; p.c0 = c0; p.x1 = x1; p.c1 = c1; p.w = weight; p.bias = bias; p.y = y;
-  p.B = batch; p.H = H; p.W = W; p.Cout = cout; p.act = act;
+  p.B = batch; p.H = H; p.W = W; p.Cout = cout; p.act = act; p.hpx = nullptr;
   const int tiles = ((W + conv::TW - 1) / conv::TW) * ((H + conv::TH - 1) / conv::TH);
   hipLaunchKernelGGL(conv::conv3x3_cyl_kernel, dim3(tiles, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_conv3x3_hpx_f32(const float* x0, int32_t c0, const float* x1, int32_t c1, const float* weight,
+                                        const float* bias, float* y, int32_t n_faces, int32_t H, int32_t W, int32_t cout,
+                                        int32_t act, const int32_t* ring_table, void* stream) {
+  DLWP_REQUIRE(x0 && weight && y && ring_table, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(n_faces > 0 && n_faces % 12 == 0, DLWP_ERR_INVALID_ARGUMENT, "n_faces=%d is not a multiple of 12", n_faces);
+  DLWP_REQUIRE(H > 0 && W > 0 && c0 > 0 && cout > 0 && c1 >= 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
+  DLWP_REQUIRE((long long)12 * H * W < (1ll << 31), DLWP_ERR_INVALID_ARGUMENT, "face too large for the 32-bit table");
+  DLWP_REQUIRE(c1 == 0 || x1, DLWP_ERR_INVALID_ARGUMENT, "second segment pointer missing");
+  DLWP_REQUIRE(act >= 0 && act <= 4, DLWP_ERR_INVALID_ARGUMENT, "unknown activation %d", act);
+  conv::Params p;
+  p.x0 = x0; p.c0 = c0; p.x1 = x1; p.c1 = c1; p.w = weight; p.bias = bias; p.y = y;
+  p.B = n_faces; p.H = H; p.W = W; p.Cout = cout; p.act = act; p.hpx = reinterpret_cast<const int2*>(ring_table);
+  const int tiles = ((W + conv::TW - 1) / conv::TW) * ((H + conv::TH - 1) / conv::TH);
+  hipLaunchKernelGGL(conv::conv3x3_cyl_kernel, dim3(tiles, n_faces), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_healpix_pad_f32(const float* x, float* y, const int32_t* table, int32_t n_faces, int32_t channels,
+                                        int32_t H, int32_t W, int32_t pad, void* stream) {
+  DLWP_REQUIRE(x && y && table, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(n_faces > 0 && n_faces % 12 == 0, DLWP_ERR_INVALID_ARGUMENT, "n_faces=%d is not a multiple of 12", n_faces);
+  DLWP_REQUIRE(channels > 0 && H > 0 && W > 0 && pad > 0 && pad <= H && pad <= W, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
+  DLWP_REQUIRE((long long)12 * (H + 2 * pad) * (W + 2 * pad) < (1ll << 31), DLWP_ERR_INVALID_ARGUMENT, "face too large");
+  const int PHW = (H + 2 * pad) * (W + 2 * pad);
+  const long long total = (long long)n_faces * channels * PHW;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(conv::healpix_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     x, y, reinterpret_cast<const int2*>(table), channels, H * W, PHW, total);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }

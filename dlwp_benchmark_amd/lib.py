@@ -67,6 +67,9 @@ SIGNATURES = {
                                       c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "dlwp_conv3x3_cyl_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "dlwp_conv3x3_hpx_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                       c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "dlwp_healpix_pad_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dlwp_convlstm_gates_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]),
     "dlwp_layernorm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_float, c_void_p]),

@@ -11,7 +11,7 @@ from .fourcastnet import AFNONet, FourCastNet
 from .pangu import PanguWeather
 from .spectral import SpectralConv2d
 from .swin import SwinTransformer
-from .unet import ConvLSTM, UNet
+from .unet import ConvLSTM, HEALPixLayer, HEALPixPadding, UNet, UNetHPX
 
 __all__ = ["FNO2DModule", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "UNet",
-           "ConvLSTM"]
+           "UNetHPX", "ConvLSTM", "HEALPixPadding", "HEALPixLayer"]

@@ -36,6 +36,38 @@ class CylinderPad(nn.Module):
         self.p = padding
 
 
+class HEALPixPadding(nn.Module):
+    """reference utils/healpix.py:165-368 as one table-driven gather kernel; x [(B*12), C, H, W]."""
+
+    def __init__(self, padding: int = 1, **kwargs):
+        super().__init__()
+        self.p = int(padding)
+        if self.p <= 0:
+            raise ValueError("padding must be positive")
+
+    def forward(self, x):
+        return ops.healpix_pad(x, self.p)
+
+
+class HEALPixLayer(nn.Module):
+    """reference utils/healpix.py:69-114 for `layer=torch.nn.Conv2d`, kernel_size 3: keeps the reference's
+    `layers = Sequential(HEALPixPadding, Conv2d(padding=0))` tree (state-dict key `layers.1.*`); executed as one
+    fused kernel by `_run_stack`, or on its own through `forward`."""
+
+    def __init__(self, layer=nn.Conv2d, **kwargs):
+        super().__init__()
+        if layer is not nn.Conv2d or kwargs.get("kernel_size", 3) != 3 or kwargs.get("dilation", 1) != 1:
+            raise NotImplementedError("only HEALPixLayer(Conv2d, kernel_size=3, dilation=1) has a fused kernel")
+        kwargs = dict(kwargs)
+        kwargs["padding"] = 0
+        kwargs.pop("enable_nhwc", None), kwargs.pop("enable_healpixpad", None)
+        self.layers = nn.Sequential(HEALPixPadding(1), nn.Conv2d(**kwargs))
+
+    def forward(self, x, act: int = 0, x1=None):
+        conv = self.layers[1]
+        return ops.conv3x3_hpx(x, conv.weight, conv.bias, act, x1=x1)
+
+
 def _resolve_activation(activation):
     if isinstance(activation, str):
         name = activation
@@ -48,6 +80,9 @@ def _resolve_activation(activation):
     return activation
 
 
+_STRUCTURAL = (CylinderPad, HEALPixLayer, nn.Conv2d, nn.ConvTranspose2d, nn.AvgPool2d)
+
+
 def _run_stack(seq: nn.Sequential, x, skip=None):
     """Executes a reference-shaped Sequential of [AvgPool] (CylinderPad, Conv2d, act)* [ConvTranspose2d]
     with each (pad, conv, act) triple fused into one kernel call; `skip` is concatenated in front
@@ -56,11 +91,18 @@ def _run_stack(seq: nn.Sequential, x, skip=None):
     i = 0
     while i < len(mods):
         m = mods[i]
-        if isinstance(m, CylinderPad):
+        if isinstance(m, HEALPixLayer):
+            act, step = 0, 1
+            if i + 1 < len(mods) and not isinstance(mods[i + 1], _STRUCTURAL):
+                act, step = ops.act_code(mods[i + 1]), 2
+            x = m(skip, act, x1=x) if skip is not None else m(x, act)
+            skip = None
+            i += step
+        elif isinstance(m, CylinderPad):
             conv = mods[i + 1]
             act = 0
             step = 2
-            if i + 2 < len(mods) and not isinstance(mods[i + 2], (CylinderPad, nn.Conv2d, nn.ConvTranspose2d, nn.AvgPool2d)):
+            if i + 2 < len(mods) and not isinstance(mods[i + 2], _STRUCTURAL):
                 act = ops.act_code(mods[i + 2])
                 step = 3
             if skip is not None:
@@ -78,8 +120,14 @@ def _run_stack(seq: nn.Sequential, x, skip=None):
     return x
 
 
+def _conv_block(c_in, c_out, activation, mesh):
+    if mesh == "healpix":
+        return [HEALPixLayer(layer=nn.Conv2d, in_channels=c_in, out_channels=c_out, kernel_size=3, padding=1), activation]
+    return [CylinderPad(1), nn.Conv2d(c_in, c_out, kernel_size=3, padding=0), activation]
+
+
 class _UNetEncoder(nn.Module):
-    def __init__(self, in_channels, hidden_channels, n_convolutions, activation):
+    def __init__(self, in_channels, hidden_channels, n_convolutions, activation, mesh="equirectangular"):
         super().__init__()
         layers = []
         channels = [in_channels] + list(hidden_channels)
@@ -90,8 +138,7 @@ class _UNetEncoder(nn.Module):
                 layer.append(nn.AvgPool2d(kernel_size=2, stride=2, padding=0))
             n_convs = n_convolutions // 2 if c_idx == len(hidden_channels) - 1 else n_convolutions
             for n_conv in range(n_convs):
-                layer += [CylinderPad(1), nn.Conv2d(c_in if n_conv == 0 else c_out, c_out, kernel_size=3, padding=0),
-                          activation]
+                layer += _conv_block(c_in if n_conv == 0 else c_out, c_out, activation, mesh)
             layers.append(nn.Sequential(*layer))
         self.layers = nn.ModuleList(layers)
 
@@ -104,7 +151,7 @@ class _UNetEncoder(nn.Module):
 
 
 class _UNetDecoder(nn.Module):
-    def __init__(self, hidden_channels, out_channels, n_convolutions, activation):
+    def __init__(self, hidden_channels, out_channels, n_convolutions, activation, mesh="equirectangular"):
         super().__init__()
         hidden = list(hidden_channels)[::-1]
         layers = []
@@ -115,8 +162,7 @@ class _UNetDecoder(nn.Module):
             n_convs = n_convolutions // 2 if c_idx == 0 else n_convolutions
             for n_conv in range(n_convs):
                 c_in_ = c_in if c_idx == 0 else 2 * hidden[c_idx]
-                layer += [CylinderPad(1), nn.Conv2d(c_in_ if n_conv == 0 else c_out, c_out, kernel_size=3, padding=0),
-                          activation]
+                layer += _conv_block(c_in_ if n_conv == 0 else c_out, c_out, activation, mesh)
             if c_idx < len(hidden) - 1:
                 layer.append(nn.ConvTranspose2d(c_out, hidden[c_idx + 1], kernel_size=2, stride=2))
             layers.append(nn.Sequential(*layer))
@@ -134,14 +180,14 @@ class UNet(HipBackbone):
                  hidden_channels: list = [8, 16, 32], n_convolutions: int = 2, activation=nn.GELU(),
                  context_size: int = 1, mesh: str = "equirectangular", **kwargs):
         super().__init__()
-        if mesh != "equirectangular":
-            raise NotImplementedError("HEALPix variant is a 'next' row (SURVEY.md 8f f3)")
+        if mesh not in ("equirectangular", "healpix"):
+            raise ValueError(f"unknown mesh {mesh!r}")
         activation = _resolve_activation(activation)
         ops.act_code(activation)  # fail early if there is no fused kernel for it
         self.context_size = int(context_size)
         in_channels = constant_channels + (prescribed_channels + prognostic_channels) * context_size
-        self.encoder = _UNetEncoder(in_channels, list(hidden_channels), n_convolutions, activation)
-        self.decoder = _UNetDecoder(list(hidden_channels), prognostic_channels, n_convolutions, activation)
+        self.encoder = _UNetEncoder(in_channels, list(hidden_channels), n_convolutions, activation, mesh)
+        self.decoder = _UNetDecoder(list(hidden_channels), prognostic_channels, n_convolutions, activation, mesh)
 
     def one_step(self, x):
         enc = self.encoder(x)
@@ -160,6 +206,48 @@ class UNet(HipBackbone):
             out = torch.empty(b, t - self.context_size, cg, h, w, device=prognostic.device, dtype=torch.float32)
             self.rollout_into(out, constants, prescribed, prognostic)
         return out
+
+
+class UNetHPX(UNet):
+    """reference models/unet/unet.py:386-426: the classic U-Net on the HEALPix mesh.  Tensors carry a face
+    axis, constants [B, 1, C, 12, H, W], prescribed / prognostic [B, T, C, 12, H, W]; faces fold into the batch
+    for the backbone (:413-426) and every HEALPixLayer(Conv2d) + activation is one dlwp_conv3x3_hpx_f32 launch."""
+
+    def __init__(self, constant_channels: int = 4, prescribed_channels: int = 0, prognostic_channels: int = 1,
+                 hidden_channels: list = [8, 16, 32], n_convolutions: int = 2, activation=nn.GELU(),
+                 context_size: int = 1, mesh: str = "healpix", **kwargs):
+        super().__init__(constant_channels=constant_channels, prescribed_channels=prescribed_channels,
+                         prognostic_channels=prognostic_channels, hidden_channels=hidden_channels,
+                         n_convolutions=n_convolutions, activation=activation, context_size=context_size, mesh="healpix")
+
+    @staticmethod
+    def _fold(t):
+        """[B, T, C, F, H, W] -> [(B F), (T C), H, W]"""
+        b, tt, c, f, h, w = t.shape
+        return t.permute(0, 3, 1, 2, 4, 5).reshape(b * f, tt * c, h, w)
+
+    def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        for name, t in (("constants", constants), ("prescribed", prescribed), ("prognostic", prognostic)):
+            if t is not None:
+                _lib.require_cuda_tensor(t, name)
+                if t.dim() != 6 or t.shape[3] != 12:
+                    raise _lib.DlwpError(f"{name}: expected [B, T, C, 12, H, W], got {tuple(t.shape)}")
+        if prognostic is None:
+            raise _lib.DlwpError("prognostic is required")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training is a 'next' row (SURVEY.md 8f f4); call .eval() / no_grad()")
+        ctx = self.context_size
+        b, t_total, cg, f, h, w = prognostic.shape
+        if t_total <= ctx:
+            raise _lib.DlwpError(f"need more than context_size={ctx} frames, got {t_total}")
+        with torch.no_grad():
+            # face-folded working layout [(B F), T, C, H, W]: the generic rollout then runs unchanged
+            fold5 = lambda t: t.permute(0, 3, 1, 2, 4, 5).reshape(b * f, t.shape[1], t.shape[2], h, w).float().contiguous()
+            out = torch.empty(b * f, t_total - ctx, cg, h, w, device=prognostic.device, dtype=torch.float32)
+            rollout_into(self.one_step, ctx, out, fold5(constants) if constants is not None else None,
+                         fold5(prescribed) if prescribed is not None else None, fold5(prognostic))
+            return out.reshape(b, f, t_total - ctx, cg, h, w).permute(0, 2, 3, 1, 4, 5).contiguous()
 
 
 class _ConvLSTMCell(nn.Module):

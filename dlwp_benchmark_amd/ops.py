@@ -106,6 +106,53 @@ def conv3x3_cyl(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return y
 
 
+def conv3x3_hpx(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
+                x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """HEALPixPadding(1) + Conv2d(3x3) + bias + activation on cat([x0, x1], 1); x [(B*12), C, H, W]."""
+    from . import healpix as _hpx
+
+    _lib.require_cuda_tensor(x0, "x0")
+    _lib.require_cuda_tensor(x1, "x1")
+    _lib.require_cuda_tensor(weight, "weight")
+    x0 = x0.contiguous()
+    x1 = x1.contiguous() if x1 is not None else None
+    weight = weight.contiguous()
+    n, c0, h, w = x0.shape
+    c1 = x1.shape[1] if x1 is not None else 0
+    cout = weight.shape[0]
+    if n % 12:
+        raise _lib.DlwpError(f"leading dimension {n} is not (batch * 12 faces)")
+    if tuple(weight.shape[1:]) != (c0 + c1, 3, 3):
+        raise _lib.DlwpError(f"weight {tuple(weight.shape)} does not match {c0}+{c1} input channels, 3x3")
+    table = _hpx.device_table(h, w, 1, x0.device)
+    y = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x0.device):
+        _lib.check(lib.dlwp_conv3x3_hpx_f32(x0.data_ptr(), c0, x1.data_ptr() if x1 is not None else None, c1,
+                                            weight.data_ptr(), bias.contiguous().data_ptr() if bias is not None else None,
+                                            y.data_ptr(), n, h, w, cout, act, table.data_ptr(), _lib.stream_ptr()),
+                   "dlwp_conv3x3_hpx_f32")
+    return y
+
+
+def healpix_pad(x: torch.Tensor, padding: int) -> torch.Tensor:
+    """HEALPixPadding(padding) (reference utils/healpix.py:165-368): [(B*12), C, H, W] -> [(B*12), C, H+2p, W+2p]."""
+    from . import healpix as _hpx
+
+    _lib.require_cuda_tensor(x, "x")
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    if n % 12:
+        raise _lib.DlwpError(f"leading dimension {n} is not (batch * 12 faces)")
+    table = _hpx.device_table(h, w, int(padding), x.device)
+    y = torch.empty(n, c, h + 2 * padding, w + 2 * padding, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_healpix_pad_f32(x.data_ptr(), y.data_ptr(), table.data_ptr(), n, c, h, w, int(padding),
+                                            _lib.stream_ptr()), "dlwp_healpix_pad_f32")
+    return y
+
+
 def convlstm_gates(gates: torch.Tensor, c_prev: torch.Tensor):
     _lib.require_cuda_tensor(gates, "gates")
     _lib.require_cuda_tensor(c_prev, "c_prev")

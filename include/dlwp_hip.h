@@ -216,6 +216,24 @@ int32_t dlwp_conv3x3_cyl_f32(const float* x0_dev, int32_t c0, const float* x1_de
                              const float* weight_dev, const float* bias_dev, float* y_dev, int32_t batch,
                              int32_t height, int32_t width, int32_t cout, int32_t act, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * HEALPix mesh.  Faces are folded into the batch, [(B*12), C, H, W], face index fastest
+ * (reference models/unet/unet.py:413-426 `b c f h w -> (b f) c h w`).  The neighbour topology of
+ * reference utils/healpix.py:165-368 (`HEALPixPadding`: rotated polar neighbours, synthesised corners) is
+ * handed over as a device table of int32 pairs (a, b): source cells face*H*W + pixel inside the same
+ * sample; b < 0 = copy a, else 0.5*a + 0.5*b.
+ *   dlwp_healpix_pad_f32: the padding layer on its own, table [12][(H+2p)*(W+2p)][2], y [(B*12), C, H+2p, W+2p].
+ *   dlwp_conv3x3_hpx_f32: HEALPixLayer(Conv2d 3x3) = HEALPixPadding(1) + Conv2d(padding 0) + bias +
+ *   activation (healpix.py:69-114) in one kernel, ring table [12][(H+2)*(W+2)][2]; other arguments as
+ *   dlwp_conv3x3_cyl_f32 with batch = n_faces = B*12.
+ * ------------------------------------------------------------------------------------------ */
+int32_t dlwp_healpix_pad_f32(const float* x_dev, float* y_dev, const int32_t* table_dev, int32_t n_faces,
+                             int32_t channels, int32_t height, int32_t width, int32_t pad, void* stream);
+int32_t dlwp_conv3x3_hpx_f32(const float* x0_dev, int32_t c0, const float* x1_dev, int32_t c1,
+                             const float* weight_dev, const float* bias_dev, float* y_dev, int32_t n_faces,
+                             int32_t height, int32_t width, int32_t cout, int32_t act,
+                             const int32_t* ring_table_dev, void* stream);
+
 /* ConvLSTM cell gate math (models/convlstm/convlstm.py:96-109): gates_dev [B, 4*hidden, H, W] in the
  * order (netin, igate, fgate, ogate), c_prev_dev [B, hidden, H, W] -> h_out_dev, c_out_dev. */
 int32_t dlwp_convlstm_gates_f32(const float* gates_dev, const float* c_prev_dev, float* h_out_dev,

@@ -171,6 +171,47 @@ def gen_models(ref, only=None):
               param_spec=np.array(json.dumps(spec)), state_spec=np.array(json.dumps(full)))
 
 
+# ------------------------------------------------------------------------------------------
+# HEALPix: padding op and the HEALPix U-Net
+# ------------------------------------------------------------------------------------------
+HPX_PAD_CASES = {"p1_8x8": (2, 3, 8, 8, 1), "p2_8x8": (1, 2, 8, 8, 2), "p1_4x4": (1, 2, 4, 4, 1)}
+HPX_MODEL_CASES = {
+    "unethpx_h4_8x8": (dict(constant_channels=4, prescribed_channels=1, prognostic_channels=3, hidden_channels=[4, 8, 16],
+                            n_convolutions=2, activation="th.nn.ReLU()", context_size=1), (2, 4), (8, 8)),
+}
+
+
+def hpx_inputs(tag, cfg, batch, frames, hw):
+    h, w = hw
+    cc, cp, cg = cfg["constant_channels"], cfg["prescribed_channels"], cfg["prognostic_channels"]
+    constants = W.normal(f"golden/hpx/{tag}/constants", (batch, 1, cc, 12, h, w), 1.0) if cc else None
+    prescribed = W.normal(f"golden/hpx/{tag}/prescribed", (batch, frames, cp, 12, h, w), 1.0) if cp else None
+    prognostic = W.normal(f"golden/hpx/{tag}/prognostic", (batch, frames, cg, 12, h, w), 1.0)
+    return constants, prescribed, prognostic
+
+
+def gen_hpx(ref):
+    import json
+
+    pad_cls = ref["utils"].HEALPixPadding
+    for tag, (b, c, h, w, p) in HPX_PAD_CASES.items():
+        x = W.normal(f"golden/hpxpad/{tag}/x", (b * 12, c, h, w), 1.0)
+        with torch.no_grad():
+            y = pad_cls(padding=p)(x)
+        _save(f"healpix_pad_{tag}", y=y.numpy(), sha=np.array(tensor_sha(x)))
+    for tag, (cfg, (batch, frames), hw) in HPX_MODEL_CASES.items():
+        m = ref["unet"].UNetHPX(**cfg)
+        m.eval()
+        sha = W.fill_state_dict(m, gain=1.0)
+        constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
+        with torch.no_grad():
+            y = m(constants=constants, prescribed=prescribed, prognostic=prognostic)
+        spec = [(k, list(v.shape)) for k, v in m.named_parameters()]
+        full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]
+        _save(f"model_{tag}", y=y.numpy().astype(np.float32), sha=np.array(sha), param_spec=np.array(json.dumps(spec)),
+              state_spec=np.array(json.dumps(full)))
+
+
 def main():
     if not ref_import.reference_available():
         raise SystemExit("reference tree not available: golden fixtures can only be regenerated in the build container")
@@ -179,7 +220,10 @@ def main():
     only = set(sys.argv[1:])
     if not only or "spectral" in only:
         gen_spectral(ref)
-    gen_models(ref, only - {"spectral"} if only else None)
+    if not only or "hpx" in only:
+        gen_hpx(ref)
+    if not only or (only - {"spectral", "hpx"}):
+        gen_models(ref, (only - {"spectral", "hpx"}) if only else None)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,123 @@
+"""CPU restatement of the HEALPix face padding and the HEALPix U-Net (TEST INFRASTRUCTURE).
+
+`healpix_pad` restates reference utils/healpix.py:165-368 (`HEALPixPadding`): every one of the 12 faces
+[..., 12, H, W] is padded by p cells taken from its 8 neighbours; polar faces contribute rotated, the two
+corners an equatorial face has no neighbour for are synthesised (`tl` :316-343, `br` :345-368: off-diagonal
+cells copied from the two adjacent faces, diagonal cells their mean).  `unet_hpx_rollout` restates
+UNetHPX (models/unet/unet.py:386-426 on top of :274-383, :429-555 with HEALPixLayer(Conv2d), healpix.py:69-114).
+PINNED by tests/golden/healpix_pad_*.npz and model_unethpx_*.npz (real reference).
+"""
+import torch
+import torch.nn.functional as F
+
+from .unet import _act
+
+
+def _rot(t, k):
+    return torch.rot90(t, k, dims=(-2, -1))
+
+
+def _synth_tl(t, l, p):
+    ret = torch.zeros_like(t)[..., :p, :p].clone()
+    ret[..., -1, -1] = 0.5 * t[..., -1, 0] + 0.5 * l[..., 0, -1]
+    for i in range(1, p):
+        ret[..., -i - 1, -i:] = t[..., -i - 1, :i]
+        ret[..., -i:, -i - 1] = l[..., :i, -i - 1]
+        ret[..., -i - 1, -i - 1] = 0.5 * t[..., -i - 1, 0] + 0.5 * l[..., 0, -i - 1]
+    return ret
+
+
+def _synth_br(b, r, p):
+    ret = torch.zeros_like(b)[..., :p, :p].clone()
+    ret[..., 0, 0] = 0.5 * b[..., 0, -1] + 0.5 * r[..., -1, 0]
+    for i in range(1, p):
+        ret[..., :i, i] = r[..., -i:, i]
+        ret[..., i, :i] = b[..., i, -i:]
+        ret[..., i, i] = 0.5 * b[..., i, -1] + 0.5 * r[..., -1, i]
+    return ret
+
+
+def healpix_pad(x, p):
+    """x [(B*12), C, H, W] -> [(B*12), C, H+2p, W+2p]."""
+    nf, c, h, w = x.shape
+    d = x.reshape(-1, 12, c, h, w)
+    f = [d[:, i] for i in range(12)]
+    out = []
+    for k in range(4):            # northern faces 0-3
+        t, tl, l, b, br, r = f[(k + 1) % 4], f[(k + 2) % 4], f[(k + 3) % 4], f[4 + k], f[8 + k], f[4 + (k + 1) % 4]
+        col = torch.cat((_rot(t, 1)[..., -p:, :], f[k], b[..., :p, :]), dim=-2)
+        left = torch.cat((_rot(tl, 2)[..., -p:, -p:], _rot(l, -1)[..., -p:], l[..., :p, -p:]), dim=-2)
+        right = torch.cat((t[..., -p:, :p], r[..., :p], br[..., :p, :p]), dim=-2)
+        out.append(torch.cat((left, col, right), dim=-1))
+    for k in range(4):            # equatorial faces 4-7
+        t, l, bl, b, r, tr = f[k], f[(k + 3) % 4], f[4 + (k + 3) % 4], f[8 + (k + 3) % 4], f[8 + k], f[4 + (k + 1) % 4]
+        col = torch.cat((t[..., -p:, :], f[4 + k], b[..., :p, :]), dim=-2)
+        left = torch.cat((_synth_tl(t, l, p)[..., -p:, -p:], l[..., -p:], bl[..., :p, -p:]), dim=-2)
+        right = torch.cat((tr[..., -p:, :p], r[..., :p], _synth_br(b, r, p)[..., :p, :p]), dim=-2)
+        out.append(torch.cat((left, col, right), dim=-1))
+    for k in range(4):            # southern faces 8-11
+        t, tl, l, b, br, r = f[4 + (k + 1) % 4], f[k], f[4 + k], f[8 + (k + 3) % 4], f[8 + (k + 2) % 4], f[8 + (k + 1) % 4]
+        col = torch.cat((t[..., -p:, :], f[8 + k], _rot(b, 1)[..., :p, :]), dim=-2)
+        left = torch.cat((tl[..., -p:, -p:], l[..., -p:], b[..., :p, -p:]), dim=-2)
+        right = torch.cat((r[..., -p:, :p], _rot(r, -1)[..., :p], _rot(br, 2)[..., :p, :p]), dim=-2)
+        out.append(torch.cat((left, col, right), dim=-1))
+    return torch.stack(out, dim=1).reshape(nf, c, h + 2 * p, w + 2 * p)
+
+
+def unet_hpx_one_step(sd, cfg, x):
+    """x [(B*12), Cin, H, W]; encoder/decoder of unet.py:429-555 with HEALPixLayer(Conv2d) blocks: the outer
+    Sequential holds (HEALPixLayer, activation) pairs, the conv weight sits at `....layers.1`."""
+    hidden = list(cfg["hidden_channels"])
+    nconv = cfg.get("n_convolutions", 2)
+    act = _act(cfg.get("activation", "th.nn.ReLU()"))
+    nl = len(hidden)
+    conv = lambda t, name: F.conv2d(healpix_pad(t, 1), sd[name + ".layers.1.weight"], sd[name + ".layers.1.bias"])
+    skips = []
+    for li in range(nl):
+        idx = 0
+        if li > 0:
+            x = F.avg_pool2d(x, 2, 2)
+            idx = 1
+        for _ in range(nconv // 2 if li == nl - 1 else nconv):
+            x = act(conv(x, f"encoder.layers.{li}.{idx}"))
+            idx += 2
+        skips.append(x)
+    skips = skips[::-1]
+    for li in range(nl):
+        if li > 0:
+            x = torch.cat([skips[li], x], dim=1)
+        idx = 0
+        for _ in range(nconv // 2 if li == 0 else nconv):
+            x = act(conv(x, f"decoder.layers.{li}.{idx}"))
+            idx += 2
+        if li < nl - 1:
+            x = F.conv_transpose2d(x, sd[f"decoder.layers.{li}.{idx}.weight"], sd[f"decoder.layers.{li}.{idx}.bias"], stride=2)
+    return F.conv2d(x, sd["decoder.output_layer.weight"], sd["decoder.output_layer.bias"])
+
+
+def unet_hpx_rollout(sd, cfg, constants, prescribed, prognostic):
+    """unet.py:331-383 with the HPX `_prepare_inputs` (:413-426): tensors carry a face axis
+    [B, T, C, 12, H, W]; faces are folded into the batch for the backbone."""
+    ctx = cfg["context_size"]
+    b = prognostic.shape[0]
+    fold_c = lambda t: t.permute(0, 2, 1, 3, 4).reshape(-1, t.shape[1], t.shape[3], t.shape[4])          # b c f h w
+    fold_t = lambda t: t.permute(0, 3, 1, 2, 4, 5).reshape(-1, t.shape[1] * t.shape[2], t.shape[4], t.shape[5])
+    outs = []
+    for t in range(ctx, prognostic.shape[1]):
+        t0 = max(0, t - ctx)
+        if t == ctx:
+            prog_t = prognostic[:, t0:t]
+            presc_t = prescribed[:, t0:t] if prescribed is not None else None
+        else:
+            prog_t = torch.cat([prognostic[:, t0:ctx], torch.stack(outs, dim=1)[:, -ctx:]], dim=1)
+            presc_t = prescribed[:, t - ctx:t] if prescribed is not None else None
+        parts = []
+        if constants is not None:
+            parts.append(fold_c(constants[:, 0]))
+        if presc_t is not None:
+            parts.append(fold_t(presc_t))
+        parts.append(fold_t(prog_t))
+        y = unet_hpx_one_step(sd, cfg, torch.cat(parts, dim=1))
+        y = y.reshape(b, 12, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)                   # b tc f h w
+        outs.append(prog_t[:, -1] + y)
+    return torch.stack(outs, dim=1)

@@ -131,3 +131,66 @@ def test_device_stager_delivers_identical_batches():
         assert (p is None) == bool(i % 2)
         if p is not None:
             assert torch.equal(p.cpu(), batches[i][1])
+
+
+# ------------------------------------------------------------------------------------------
+# HEALPix row
+# ------------------------------------------------------------------------------------------
+def _hpx_pad_cases():
+    from oracle.make_golden import HPX_PAD_CASES
+
+    return list(HPX_PAD_CASES)
+
+
+@pytest.mark.parametrize("tag", _hpx_pad_cases())
+def test_healpix_padding_kernel_matches_reference_golden(tag):
+    """Pure data movement (+ exact halves): bit-exact against the real HEALPixPadding output."""
+    from dlwp_benchmark_amd import ops
+    from dlwp_benchmark_amd import weights as W
+    from oracle.make_golden import HPX_PAD_CASES
+
+    b, c, h, w, p = HPX_PAD_CASES[tag]
+    x = W.normal(f"golden/hpxpad/{tag}/x", (b * 12, c, h, w), 1.0)
+    y = ops.healpix_pad(x.to("cuda:0"), p).cpu()
+    assert torch.equal(y, torch.from_numpy(load_golden(f"healpix_pad_{tag}")["y"]))
+
+
+def test_healpix_conv_kernel_matches_pad_then_conv():
+    """Fused HEALPixLayer(Conv2d) incl. two-segment input and faces larger than one tile, vs the oracle
+    padding followed by torch conv2d on the CPU."""
+    import torch.nn.functional as F
+
+    from dlwp_benchmark_amd import ops
+    from oracle.restate.healpix import healpix_pad
+
+    g = torch.Generator().manual_seed(5)
+    for (b, c0, c1, co, n) in ((1, 5, 0, 7, 16), (2, 3, 6, 20, 40)):
+        x0 = torch.randn(b * 12, c0, n, n, generator=g)
+        x1 = torch.randn(b * 12, c1, n, n, generator=g) if c1 else None
+        wt = torch.randn(co, c0 + c1, 3, 3, generator=g) / (3.0 * (c0 + c1) ** 0.5)
+        bias = torch.randn(co, generator=g)
+        xin = torch.cat([x0, x1], 1) if c1 else x0
+        want = F.relu(F.conv2d(healpix_pad(xin.double(), 1), wt.double(), bias.double()))
+        got = ops.conv3x3_hpx(x0.cuda(), wt.cuda(), bias.cuda(), ops.act_code(torch.nn.ReLU()),
+                              x1=x1.cuda() if c1 else None)
+        assert rel_l2(got, want) < 2e-6
+
+
+def test_unet_hpx_rollout_matches_reference_golden():
+    import dlwp_benchmark_amd.models as M
+    from dlwp_benchmark_amd.weights import fill_by_spec
+    from oracle.make_golden import HPX_MODEL_CASES, hpx_inputs
+
+    for tag, (cfg, (batch, frames), hw) in HPX_MODEL_CASES.items():
+        g = load_golden(f"model_{tag}")
+        sd, sha = fill_by_spec(json.loads(str(g["param_spec"])), gain=1.0)
+        assert sha == str(g["sha"])
+        model = M.UNetHPX(**cfg)
+        model.load_state_dict(sd, strict=True)
+        model = model.to("cuda:0").eval()
+        dev = lambda t: t.to("cuda:0") if t is not None else None
+        got = model(*[dev(t) for t in hpx_inputs(tag, cfg, batch, frames, hw)])
+        want = torch.from_numpy(g["y"])
+        assert got.shape == want.shape
+        errs = per_step_rel_l2(got, want)
+        assert max(errs) <= TOL, f"{tag}: per-step rel L2 {['%.2e' % e for e in errs]}"

@@ -75,3 +75,32 @@ def test_state_dicts_match_reference_layout():
         assert got == want, (tag, sorted(set(want) ^ set(got))[:6])
         checked += 1
     assert checked >= 3
+    from oracle.make_golden import HPX_MODEL_CASES
+
+    for tag, (cfg, _, _) in HPX_MODEL_CASES.items():
+        g = load_golden(f"model_{tag}")
+        want = {k: (tuple(s), d) for k, s, d in json.loads(str(g["state_spec"]))}
+        got = {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in M.UNetHPX(**cfg).state_dict().items()}
+        assert got == want, (tag, sorted(set(want) ^ set(got))[:6])
+
+
+def test_healpix_gather_table_reproduces_reference_padding():
+    """Host logic of the HEALPix row: the gather table (dlwp_benchmark_amd/healpix.py), applied with plain
+    indexing on the CPU, reproduces the real reference HEALPixPadding outputs bit for bit."""
+    import torch
+
+    from dlwp_benchmark_amd import weights as W
+    from dlwp_benchmark_amd.healpix import pad_table
+    from helpers import load_golden
+    from oracle.make_golden import HPX_PAD_CASES
+
+    for tag, (b, c, h, w, p) in HPX_PAD_CASES.items():
+        x = W.normal(f"golden/hpxpad/{tag}/x", (b * 12, c, h, w), 1.0)
+        t = pad_table(h, w, p).long()
+        assert t.shape == (12, (h + 2 * p) * (w + 2 * p), 2) and int(t[..., 0].min()) >= 0 and int(t.max()) < 12 * h * w
+        xs = x.reshape(b, 12, c, h * w).permute(0, 2, 1, 3).reshape(b, c, 12 * h * w)
+        ia, ib = t[..., 0].reshape(-1), t[..., 1].reshape(-1)
+        va, vb = xs[:, :, ia], xs[:, :, ib.clamp(min=0)]
+        y = torch.where(ib >= 0, 0.5 * va + 0.5 * vb, va)
+        y = y.reshape(b, c, 12, h + 2 * p, w + 2 * p).permute(0, 2, 1, 3, 4).reshape(b * 12, c, h + 2 * p, w + 2 * p)
+        assert torch.equal(y, torch.from_numpy(load_golden(f"healpix_pad_{tag}")["y"])), tag
