@@ -225,13 +225,27 @@ def main():
                 "TFLOPs": w_["flops"] / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None,
                 "share_of_rollout": avg_ms * launches / ms_per_step,
             }
-        # the kernel the north star names (spectral-conv layer, HBM-bound)
+        # the kernel the north star names (spectral-conv layer, HBM-bound).  With the fused trunk
+        # (fno_trunk_kernel, the default at this config) ONE launch runs all n_layers spectral layers
+        # including their mode mixing, so the algorithmic bytes of a launch are n_layers x the per-layer
+        # figure of SURVEY.md 8(d) (4 * P * 2 * Ch + skip weights) plus the spectral weights it reads.
         lay = per_kernel["layer"]
+        fused = per_kernel["modes"]["launches_per_rollout"] == 0
+        kname = "fno_trunk_kernel" if fused else "fno_layer_kernel"
+        if fused:
+            nl = MODEL_KW["n_layers"]
+            lay_bytes = nl * (work["layer"]["bytes"] + work["modes"]["bytes"])
+            lay_flops = nl * (work["layer"]["flops"] + work["modes"]["flops"])
+            lay["GBps"] = lay_bytes / (lay["avg_ms"] * 1e-3) / 1e9
+            lay["TFLOPs"] = lay_flops / (lay["avg_ms"] * 1e-3) / 1e12
+            lay["spectral_layers_per_launch"] = nl
+        else:
+            lay_bytes = work["layer"]["bytes"]
         result["roofline"] = {
-            "kernel": "fno_layer_kernel", "bound": "hbm", "achieved": lay["GBps"], "peak": HBM_PEAK_GBS,
+            "kernel": kname, "bound": "hbm", "achieved": lay["GBps"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": lay["GBps"] / HBM_PEAK_GBS if lay["GBps"] else None,
-            "traffic": (traffic or {}).get("fno_layer_kernel"),
-            "algorithmic_bytes_per_launch": work["layer"]["bytes"], "avg_launch_ms": lay["avg_ms"],
+            "traffic": (traffic or {}).get(kname),
+            "algorithmic_bytes_per_launch": lay_bytes, "avg_launch_ms": lay["avg_ms"],
             "timing": "HIP events on the launch stream around every launch of the timed rollout; one event-marker "
                       f"latency (half of an empty bracket, {0.5 * event_overhead_ms * 1e3:.2f} us) subtracted",
         }

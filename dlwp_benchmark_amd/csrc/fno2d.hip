@@ -1032,6 +1032,435 @@ __global__ __launch_bounds__(1024) void fno_modes_kernel(const ModesParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused trunk: ALL spectral layers of one backbone step in one launch (W = 64, H % 8 == 0, KP = 16).
+//
+// One workgroup = 8 consecutive grid rows of one sample, one wave per row; the G = H/8 workgroups of a
+// sample form a group and every workgroup of the grid is resident at once (one per CU).  The hidden
+// activation of a row (32 channels x 64 pixels) lives in 32 VGPRs of its wave from the first layer to the
+// last: it is read from HBM/Infinity Cache once and written once per STEP instead of once per layer.
+// What crosses workgroups is only the spectrum, M1 x M2 x 32 complex numbers per sample and layer:
+//
+//   per layer   P1  X_part[r][ky][c] = sum over this workgroup's 8 rows of EF[r][h] * Y[h][ky][c]   (MFMA, LDS)
+//               -- group barrier --                 (X_part published with agent-scope sc1 stores)
+//               P2  the group's M1*M2 modes are dealt out to its workgroups: sum the G partials,
+//                   O[r][ky][o] = fwd_scale * sum_c X[r][ky][c] * Wt[ky][r][c][o]
+//               -- group barrier --
+//               P3  Z[h][ky][o] = ck[ky] * sum_r EI[r][h] * O[r][ky][o] for the 8 own rows          (MFMA -> LDS)
+//               row y = act(bias + Wskip * x + Z * T)   skip conv on the bf16 pipe (bf16x6, B operand
+//                   taken straight from the resident registers), inverse W-DFT on fp32 MFMA, packed GELU;
+//                   forward W-DFT of the result -> Y row in LDS for the next layer
+//
+// The group barrier is an agent-scope counter: stores drained (s_waitcnt vmcnt(0)) + workgroup barrier,
+// one lane adds and polls (bounded: a timeout poisons the output with NaN instead of hanging the GPU).
+// Handed-off data is written and read with relaxed agent-scope atomics (sc1: write-through, L1 bypass);
+// tools/ubench_groupsync.hip measures 1.3-1.6 us per barrier, 2.1 us with the payload when the group shares
+// an XCD (workgroup i runs on XCD i % 8, so a sample's workgroups are i, i+8, ...).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTrunkMaxLayers = 8;
+constexpr int kSyStride = 528;   // floats per Y row in LDS: 16 k' x 32 c + 16 (bank spread for the P1 B reads)
+
+struct TrunkParams {
+  const float* x;      // [B][32][H][64] hidden activation from the lifting kernel
+  float* y;            // [B][32][H][64] output for the projection kernel
+  const float* ybuf;   // [B][H][16][32] W-direction DFT of x (emitted by the lifting kernel)
+  const float* t;      // T[16][64]
+  const float* tt;     // TT[64][16]
+  const float2* ef;    // [M1][H]
+  const float2* ei;    // [M1][H]
+  const float* ck;     // [M2]
+  const u32x4* wsb[kTrunkMaxLayers];   // skip weights, bf16x3 A operands with the k order of the resident layout
+  const float* bias[kTrunkMaxLayers];
+  const float2* wt[kTrunkMaxLayers];   // [M2][M1][32][32]
+  float* xpart;        // [S][G][M2][M1][2][32]
+  float* obuf;         // [S][M2][M1][2][32]
+  unsigned* ctr;       // one counter per sample, 32 dwords apart
+  unsigned epoch;      // barriers already counted on these counters
+  float fwd_scale;
+  int S, H, L, M1, M2, G, sample0;
+  unsigned long long* trace;   // diagnostics (DLWP_TRUNK_TRACE): [workgroup][64] s_memrealtime stamps, or null
+};
+
+__device__ __forceinline__ void trunk_group_barrier(unsigned* ctr, unsigned target, int* s_fail) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);   // this wave's sc1 stores have reached the coherence point
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 17)) {   // ~ 0.1 s: a peer workgroup never arrived; give up loudly, never hang
+        *s_fail = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Split form: arrive (stores drained, one lane adds) ... independent work ... wait.
+__device__ __forceinline__ void trunk_group_arrive(unsigned* ctr) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void trunk_group_wait(unsigned* ctr, unsigned target, int* s_fail) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 17)) {
+        *s_fail = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Four independent 16-byte agent-scope (sc1: L1 bypass) loads in flight at once, then one wait.  hipcc puts
+// `s_waitcnt vmcnt(0)` behind EVERY relaxed atomic load, which turned the 12-16 hand-off loads of a phase into
+// as many serialized round trips to the Infinity Cache (first version of this kernel: P2 4.3 us, P3 2.9 us).
+__device__ __forceinline__ void ld4_sc1_x4(const float* base, unsigned o0, unsigned o1, unsigned o2, unsigned o3,
+                                           f32x4& v0, f32x4& v1, f32x4& v2, f32x4& v3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, %8 sc1\n\t"
+      "global_load_dwordx4 %1, %5, %8 sc1\n\t"
+      "global_load_dwordx4 %2, %6, %8 sc1\n\t"
+      "global_load_dwordx4 %3, %7, %8 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+      : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base)
+      : "memory");
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the
+// weight prefetches that are meant to stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ f32x4 shfl_xor4(f32x4 v, int m) {
+  return f32x4{__shfl_xor(v[0], m), __shfl_xor(v[1], m), __shfl_xor(v[2], m), __shfl_xor(v[3], m)};
+}
+
+template <int G>   // workgroups per sample = H / 8
+__global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int W = 64, KP = 16, C = kC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  float* s_tr = smem + wave * (C * kTrStride);            // [8][32][68]   per-wave transpose tile
+  float* s_y = smem + 8 * C * kTrStride;                  // [8][528]      Y rows of this workgroup
+  float* s_z = s_y + 8 * kSyStride;                       // [8][16][32]   Z rows of this workgroup
+  float* s_x = s_z + 8 * KP * C;                          // [8][2][64]    per-wave reduced X of two modes
+  float* s_t = s_x + 8 * 128;                             // [16][64]      T  (inverse W-DFT twiddles)
+  float* s_tt = s_t + KP * W;                             // [64][16]      TT (forward W-DFT twiddles)
+  int* s_fail = reinterpret_cast<int*>(s_tt + W * KP);
+  const int H = p.H, M1 = p.M1, M2 = p.M2, NM = M1 * M2;
+  int sample, member;
+  {
+    const int i = blockIdx.x;
+    if ((p.S & 7) == 0) {          // a sample's workgroups share an XCD (workgroup i -> XCD i % 8)
+      const int slot = i >> 3;
+      sample = (i & 7) + 8 * (slot / G);
+      member = slot % G;
+    } else {
+      sample = i / G;
+      member = i % G;
+    }
+  }
+  const int h = member * 8 + wave;
+  const long long HW = (long long)H * W;
+  const int gs = p.sample0 + sample;                      // sample index in the activation tensors
+  const long long pix = (long long)h * W + 4 * j;
+  unsigned* ctr = p.ctr + sample * 32;
+  if (tid == 0) *s_fail = 0;
+  for (int i = tid; i < 8 * KP * C; i += 512) s_z[i] = 0.f;   // k' slots beyond 2*M2 stay zero
+  for (int i = tid; i < KP * W; i += 512) {
+    s_t[i] = p.t[i];
+    s_tt[i] = p.tt[i];
+  }
+
+  // resident activation: vv[ot][r] = channel 16 ot + 4 g + r, pixels 4j..4j+3
+  f32x4 vv[2][4];
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      vv[ot][r] = *reinterpret_cast<const f32x4*>(p.x + ((long long)gs * C + 16 * ot + 4 * g + r) * HW + pix);
+  {
+    const float* yr = p.ybuf + ((long long)gs * H + h) * KP * C;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + 4 * lane + 256 * u) =
+          *reinterpret_cast<const f32x4*>(yr + 4 * lane + 256 * u);
+  }
+  // loop-invariant operands
+  float a_re[4], a_im[4];   // P1: A[(r = j)][k = (hl, ri)], hl = 2s + (g >> 1), ri = g & 1
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int hl = 2 * s + (g >> 1);
+    float2 e = {0.f, 0.f};
+    if (j < M1) e = p.ef[j * H + member * 8 + hl];
+    a_re[s] = (g & 1) ? -e.y : e.x;
+    a_im[s] = (g & 1) ? e.x : e.y;
+  }
+  float a3[8];              // P3: A[m = (hl = j >> 1, ro = j & 1)][k = (r, ri)], r = 2s + (g >> 1), ri = g & 1
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int r = 2 * s + (g >> 1);
+    float2 e = {0.f, 0.f};
+    if (r < M1) e = p.ei[r * H + member * 8 + (j >> 1)];
+    a3[s] = (j & 1) ? ((g & 1) ? e.x : e.y) : ((g & 1) ? -e.y : e.x);
+  }
+  const int ks3 = (2 * M1 + 3) / 4;
+  const float ckw = wave < M2 ? p.ck[wave] : 0.f;
+  const int per = (NM + G - 1) / G;                       // modes per workgroup in P2
+  const int m_lo = member * per, m_hi = (m_lo + per < NM) ? m_lo + per : NM;
+  float* xp_mine = p.xpart + ((long long)sample * G + member) * NM * 64;
+  const float* xp_grp = p.xpart + (long long)sample * G * NM * 64;
+  float* ob = p.obuf + (long long)sample * NM * 64;
+  unsigned target = p.epoch * (unsigned)G;
+  int n_stamp = 0;
+#define DLWP_STAMP()                                                                                   \
+  do {                                                                                                 \
+    if (p.trace && tid == 0 && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+  DLWP_STAMP();
+
+  for (int l = 0; l < p.L; ++l) {
+    // operands that do not depend on data are requested before the barriers: the skip weights / bias of the row
+    // phase and the weights of this wave's first two modes
+    u32x4 wb[2][3];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) wb[ot][pp] = p.wsb[l][(ot * 3 + pp) * 64 + lane];
+    f32x4 bias4[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) bias4[ot] = *reinterpret_cast<const f32x4*>(p.bias[l] + 16 * ot + 4 * g);
+    float2 wreg[2][16];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m_lo + wave + 8 * u;
+      const float2* w = p.wt[l] + ((long long)(m < m_hi ? m : 0) * C + (lane >> 5) * 16) * C + (lane & 31);
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) wreg[u][cc] = w[cc * C];
+    }
+    lds_barrier();   // s_y complete (all 8 rows)
+    DLWP_STAMP();
+    // ---- P1: partial H-direction DFT of the 8 own rows, columns (ky = wave, c)
+    if (wave < M2) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 dre = {0.f, 0.f, 0.f, 0.f}, dim = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float b = s_y[(2 * s + (g >> 1)) * kSyStride + (2 * wave + (g & 1)) * C + 16 * nt + j];
+          dre = mfma16x16x4(a_re[s], b, dre);
+          dim = mfma16x16x4(a_im[s], b, dim);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int r = 4 * g + r4;
+          if (r < M1) {
+            float* dst = xp_mine + (long long)(wave * M1 + r) * 64 + 16 * nt + j;
+            st_sc1(dst, dre[r4]);
+            st_sc1(dst + 32, dim[r4]);
+          }
+        }
+      }
+    }
+    DLWP_STAMP();
+    target += (unsigned)G;
+    trunk_group_arrive(ctr);
+    // in the shadow of the barrier: the part of the row that does not need the spectrum, bias + 1x1 skip
+    // convolution of the resident activation on the bf16 pipe (bf16x6)
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[ot][q] = bias4[ot];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u32x4 bx[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned hh, mm, ll;
+        split3_pair(vv[i >> 1][2 * (i & 1)][q], vv[i >> 1][2 * (i & 1) + 1][q], hh, mm, ll);
+        bx[0][i] = hh;
+        bx[1][i] = mm;
+        bx[2][i] = ll;
+      }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma_bf16x6(wb[ot], bx, acc[ot][q]);
+    }
+    trunk_group_wait(ctr, target, s_fail);
+    DLWP_STAMP();
+    // ---- P2: channel mixing of this workgroup's share of the modes, two modes per pass.
+    // lane (q4 = lane >> 4, quad = lane & 15) fetches floats 4 quad..4 quad+3 of the partials q4, q4+4, ...
+    for (int up = 0; up < 2; ++up) {
+      const int ma = m_lo + wave + 16 * up, mb = ma + 8;
+      if (ma >= m_hi) break;
+      const bool has_b = mb < m_hi;
+      const int q4 = lane >> 4, quad = lane & 15;
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
+      constexpr int NI = (G + 3) / 4;   // partials per lane and mode
+#pragma unroll
+      for (int i0 = 0; i0 < NI; i0 += 2) {
+        const int qa = q4 + 4 * i0, qb = q4 + 4 * (i0 + 1);
+        const bool va = qa < G, vb = (i0 + 1 < NI) && qb < G;
+        const unsigned oa0 = (unsigned)((((va ? qa : 0) * NM + ma) * 64 + 4 * quad) * 4);
+        const unsigned oa1 = (unsigned)((((vb ? qb : 0) * NM + ma) * 64 + 4 * quad) * 4);
+        const unsigned ob0 = (unsigned)((((va ? qa : 0) * NM + (has_b ? mb : ma)) * 64 + 4 * quad) * 4);
+        const unsigned ob1 = (unsigned)((((vb ? qb : 0) * NM + (has_b ? mb : ma)) * 64 + 4 * quad) * 4);
+        f32x4 v0, v1, v2, v3;
+        ld4_sc1_x4(xp_grp, oa0, oa1, ob0, ob1, v0, v1, v2, v3);
+        if (va) { sa += v0; sb += v2; }
+        if (vb) { sa += v1; sb += v3; }
+      }
+      sa += shfl_xor4(sa, 16);
+      sb += shfl_xor4(sb, 16);
+      sa += shfl_xor4(sa, 32);
+      sb += shfl_xor4(sb, 32);
+      if (lane < 16) {
+        *reinterpret_cast<f32x4*>(s_x + wave * 128 + 4 * quad) = sa * p.fwd_scale;
+        *reinterpret_cast<f32x4*>(s_x + wave * 128 + 64 + 4 * quad) = sb * p.fwd_scale;
+      }
+      wave_lds_fence();
+      const int c0 = (lane >> 5) * 16;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int m = a ? mb : ma;
+        if (a && !has_b) break;
+        const float* xr = s_x + wave * 128 + a * 64;
+        float2 acc = {0.f, 0.f};
+        if (up == 0) {
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) acc = cfma(float2{xr[c0 + cc], xr[32 + c0 + cc]}, wreg[a][cc], acc);
+        } else {
+          const float2* w = p.wt[l] + ((long long)m * C + c0) * C + (lane & 31);
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) acc = cfma(float2{xr[c0 + cc], xr[32 + c0 + cc]}, w[cc * C], acc);
+        }
+        acc.x += __shfl_xor(acc.x, 32);
+        acc.y += __shfl_xor(acc.y, 32);
+        st_sc1(ob + (long long)m * 64 + lane, lane < 32 ? acc.x : acc.y);
+      }
+      wave_lds_fence();
+    }
+    DLWP_STAMP();
+    target += (unsigned)G;
+    trunk_group_barrier(ctr, target, s_fail);
+    DLWP_STAMP();
+    // ---- P3: inverse H-direction DFT for the 8 own rows, columns (ky = wave, o) -> s_z
+    if (wave < M2) {
+      // O[ky = wave][r][re/im][o]: M1 * 64 floats, fetched with coalesced 16-byte loads into the (idle) transpose tile
+      {
+        const int nflt = M1 * 64;
+        unsigned o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = 4 * lane + 256 * i;
+          o[i] = (unsigned)((wave * nflt + (f < nflt ? f : 0)) * 4);
+        }
+        f32x4 v0, v1, v2, v3;
+        ld4_sc1_x4(ob, o[0], o[1], o[2], o[3], v0, v1, v2, v3);
+        *reinterpret_cast<f32x4*>(s_tr + 4 * lane) = v0;
+        *reinterpret_cast<f32x4*>(s_tr + 4 * lane + 256) = v1;
+        *reinterpret_cast<f32x4*>(s_tr + 4 * lane + 512) = v2;
+        *reinterpret_cast<f32x4*>(s_tr + 4 * lane + 768) = v3;
+        wave_lds_fence();
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          if (s < ks3) {
+            const int r = 2 * s + (g >> 1);
+            const float b = r < M1 ? s_tr[r * 64 + (g & 1) * 32 + 16 * nt + j] : 0.f;
+            d = mfma16x16x4(a3[s], b, d);
+          }
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          s_z[(2 * g + (r4 >> 1)) * (KP * C) + (2 * wave + (r4 & 1)) * C + 16 * nt + j] = d[r4] * ckw;
+      }
+    }
+    lds_barrier();
+    DLWP_STAMP();
+    // ---- the row itself
+    float z[KP / 4][2];
+#pragma unroll
+    for (int s = 0; s < KP / 4; ++s)
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) z[s][ot] = s_z[wave * (KP * C) + (4 * s + g) * C + 16 * ot + j];
+#pragma unroll
+    for (int s = 0; s < KP / 4; ++s) {
+      const f32x4 tw = *reinterpret_cast<const f32x4*>(s_t + (4 * s + g) * W + 4 * j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma16x16x4(z[s][ot], tw[q], acc[ot][q]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[ot][r] = f32x4{acc[ot][0][r], acc[ot][1][r], acc[ot][2][r], acc[ot][3][r]};
+    DLWP_STAMP();
+    if (l < p.L - 1) {
+      // neuralop FNOBlocks.forward_with_postactivation: GELU after every layer but the last
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        gelu_erf8(vv[ot][0], vv[ot][1]);
+        gelu_erf8(vv[ot][2], vv[ot][3]);
+      }
+      DLWP_STAMP();
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<f32x4*>(s_tr + (16 * ot + 4 * g + r) * kTrStride + 4 * j) = vv[ot][r];
+      wave_lds_fence();
+      DLWP_STAMP();
+      f32x4 yacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          yacc[ct] = mfma16x16x4(s_tr[(16 * ct + j) * kTrStride + 4 * s + g], s_tt[(4 * s + g) * KP + j], yacc[ct]);
+      wave_lds_fence();
+      DLWP_STAMP();
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + j * C + 16 * ct + 4 * g) = yacc[ct];
+    }
+  }
+  DLWP_STAMP();
+#undef DLWP_STAMP
+  if (*s_fail) {
+    const float nanv = __uint_as_float(0x7fc00000u);
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[ot][r] = f32x4{nanv, nanv, nanv, nanv};
+  }
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(p.y + ((long long)gs * C + 16 * ot + 4 * g + r) * HW + pix) = vv[ot][r];
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 struct SpectralCore {  // what one spectral convolution stage needs on the device
@@ -1197,7 +1626,7 @@ struct dlwp_fno2d_plan {
   DevBuf lift_w1p, lift_b1, lift_w2p, lift_b2, lift_w2b;
   DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v, proj_w1b;
   int proj_co = 0;  // outputs handled by pw_proj_small_kernel (1, 2 or 4), 0 = generic MFMA path
-  std::vector<DevBuf> wt, wsp, sbias, wsb;
+  std::vector<DevBuf> wt, wsp, sbias, wsb, wsbp;   // wsbp: bf16x3 skip weights in the trunk kernel's k order
 };
 
 static void pack_w1(std::vector<float>& dst, const float* w1, int hid, int cin, int cin_steps) {
@@ -1325,7 +1754,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
     for (int i = 0; i < p->cout; ++i) b2[i] = d->proj_b2[i];
     if ((e = up(p->proj_b2, b2)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
-    p->wt.resize(p->L); p->wsp.resize(p->L); p->sbias.resize(p->L); p->wsb.resize(p->L);
+    p->wt.resize(p->L); p->wsp.resize(p->L); p->sbias.resize(p->L); p->wsb.resize(p->L); p->wsbp.resize(p->L);
     for (int l = 0; l < p->L && e == hipSuccess; ++l) {
       std::vector<float> w((size_t)d->n_cols * d->n_rows * kC * kC * 2, 0.f);
       pack_spectral(w, d->spec_w[l], kC, kC, d->n_rows, d->n_cols, d->n_rows, 0);
@@ -1339,6 +1768,19 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
       std::vector<uint32_t> wsb;
       pack_a_bf16x3(wsb, d->skip_w[l], kC, kC);
       if ((e = p->wsb[l].upload(wsb.data(), wsb.size() * 4, s)) != hipSuccess) break;
+      {
+        // fno_trunk_kernel takes the B operand from its resident registers: k-slot 8g + c' is channel
+        // 16 (c' >> 2) + 4 g + (c' & 3)
+        std::vector<float> wperm((size_t)kC * kC);
+        for (int o = 0; o < kC; ++o)
+          for (int k = 0; k < kC; ++k) {
+            const int gg = k >> 3, cp = k & 7;
+            wperm[(size_t)o * kC + k] = d->skip_w[l][(size_t)o * kC + 16 * (cp >> 2) + 4 * gg + (cp & 3)];
+          }
+        std::vector<uint32_t> wsbp;
+        pack_a_bf16x3(wsbp, wperm.data(), kC, kC);
+        if ((e = p->wsbp[l].upload(wsbp.data(), wsbp.size() * 4, s)) != hipSuccess) break;
+      }
       if ((e = p->sbias[l].upload(d->spec_b + (size_t)l * kC, (size_t)kC * 4, s)) != hipSuccess) break;
       if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
     }
@@ -1397,8 +1839,11 @@ struct KernelTimer {
 };
 struct FnoWorkspace {
   float *h0, *h1, *ybuf, *zbuf;
+  float *xpart, *obuf;   // fused trunk: per-workgroup spectrum partials, mixed spectrum
+  unsigned* ctr;         // fused trunk: one group counter per sample (128 B apart)
   size_t total;
 };
+constexpr size_t kCtrStrideBytes = 128;
 FnoWorkspace carve(const dlwp_fno2d_plan* p, int B, void* base) {
   FnoWorkspace w;
   const size_t act = align_up((size_t)B * kC * p->H * p->W * 4, 256);
@@ -1408,7 +1853,14 @@ FnoWorkspace carve(const dlwp_fno2d_plan* p, int B, void* base) {
   w.h1 = reinterpret_cast<float*>(c + act);
   w.ybuf = reinterpret_cast<float*>(c + 2 * act);
   w.zbuf = reinterpret_cast<float*>(c + 2 * act + yz);
-  w.total = 2 * act + 2 * yz;
+  const int G = (p->H + 7) / 8;
+  const size_t nm = (size_t)p->sc.M1 * p->sc.M2 * 64 * 4;
+  const size_t xp = align_up((size_t)B * G * nm, 256), ob = align_up((size_t)B * nm, 256);
+  const size_t ct = align_up((size_t)B * kCtrStrideBytes, 256);
+  w.xpart = reinterpret_cast<float*>(c + 2 * act + 2 * yz);
+  w.obuf = reinterpret_cast<float*>(c + 2 * act + 2 * yz + xp);
+  w.ctr = reinterpret_cast<unsigned*>(c + 2 * act + 2 * yz + xp + ob);
+  w.total = 2 * act + 2 * yz + xp + ob + ct;
   return w;
 }
 
@@ -1433,10 +1885,104 @@ int32_t launch_lift_cs(const MlpParams& mp, int kp, int grid, size_t lds, hipStr
   return DLWP_OK;
 }
 
+// Fused trunk (fno_trunk_kernel): eligibility, counter reset, launch.
+int device_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+  }();
+  return n;
+}
+bool trunk_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("DLWP_FNO_TRUNK");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+constexpr size_t kTrunkLds = ((size_t)8 * kC * kTrStride + 8 * kSyStride + 8 * 16 * kC + 8 * 128 + 2 * 16 * 64 + 4) * sizeof(float);
+bool trunk_eligible(const dlwp_fno2d_plan* p) {
+  if (!trunk_enabled() || !use_bf16x6()) return false;
+  const int G = p->H / 8;
+  if (p->W != 64 || p->H % 8 != 0 || p->sc.KP != 16 || p->sc.M1 > 16 || p->L > kTrunkMaxLayers) return false;
+  if (G != 4 && G != 8 && G != 16) return false;              // instantiated group sizes (H = 32, 64, 128)
+  if ((p->sc.M1 * p->sc.M2 + G - 1) / G > 32) return false;   // at most 4 modes per wave in P2
+  return G <= device_cu_count();   // a sample's group must be resident at once (one workgroup per CU)
+}
+struct TrunkState {
+  bool on = false;
+  unsigned epoch = 0;   // group barriers already counted since the counters were zeroed
+};
+int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, TrunkState& st, hipStream_t s) {
+  st.on = trunk_eligible(p);
+  st.epoch = 0;
+  if (st.on) DLWP_HIP_CHECK(hipMemsetAsync(ws.ctr, 0, (size_t)B * kCtrStrideBytes, s));
+  return DLWP_OK;
+}
+int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, const float* hin, float* hout,
+                     TrunkState& st, hipStream_t s) {
+  const int G = p->H / 8;
+  int per_launch = device_cu_count() / G;
+  if (per_launch >= 8) per_launch &= ~7;   // keeps the same-XCD group mapping
+  DLWP_REQUIRE(per_launch > 0, DLWP_ERR_UNSUPPORTED, "a sample needs %d workgroups, more than the device has CUs", G);
+  DLWP_HIP_CHECK(allow_lds(fno_trunk_kernel<4>, kTrunkLds));
+  DLWP_HIP_CHECK(allow_lds(fno_trunk_kernel<8>, kTrunkLds));
+  DLWP_HIP_CHECK(allow_lds(fno_trunk_kernel<16>, kTrunkLds));
+  const size_t nm = (size_t)p->sc.M1 * p->sc.M2 * 64;
+  for (int s0 = 0; s0 < B; s0 += per_launch) {
+    TrunkParams tp;
+    tp.x = hin; tp.y = hout; tp.ybuf = ws.ybuf;
+    tp.t = p->sc.t.as<float>(); tp.tt = p->sc.tt.as<float>();
+    tp.ef = p->sc.ef.as<float2>(); tp.ei = p->sc.ei.as<float2>(); tp.ck = p->sc.ck.as<float>();
+    for (int l = 0; l < kTrunkMaxLayers; ++l) {
+      const int ll = l < p->L ? l : 0;
+      tp.wsb[l] = p->wsbp[ll].as<u32x4>(); tp.bias[l] = p->sbias[ll].as<float>(); tp.wt[l] = p->wt[ll].as<float2>();
+    }
+    tp.S = (B - s0 < per_launch) ? B - s0 : per_launch;
+    tp.xpart = ws.xpart + (size_t)s0 * G * nm;
+    tp.obuf = ws.obuf + (size_t)s0 * nm;
+    tp.ctr = ws.ctr + (size_t)s0 * (kCtrStrideBytes / 4);
+    tp.epoch = st.epoch; tp.fwd_scale = p->sc.fwd_scale;
+    tp.H = p->H; tp.L = p->L; tp.M1 = p->sc.M1; tp.M2 = p->sc.M2; tp.G = G; tp.sample0 = s0;
+    // diagnostics: DLWP_TRUNK_TRACE=<file> dumps per-workgroup phase timestamps of the first few launches
+    static const char* trace_path = getenv("DLWP_TRUNK_TRACE");
+    static unsigned long long* trace_buf = nullptr;
+    static int traced = 0;
+    tp.trace = nullptr;
+    if (trace_path && traced < 4) {
+      if (!trace_buf) DLWP_HIP_CHECK(hipMalloc(&trace_buf, (size_t)1024 * 64 * 8));
+      DLWP_HIP_CHECK(hipMemsetAsync(trace_buf, 0, (size_t)1024 * 64 * 8, s));
+      if (tp.S * G <= 1024) tp.trace = trace_buf;
+    }
+    if (G == 4) hipLaunchKernelGGL(fno_trunk_kernel<4>, dim3(tp.S * G), dim3(512), kTrunkLds, s, tp);
+    else if (G == 8) hipLaunchKernelGGL(fno_trunk_kernel<8>, dim3(tp.S * G), dim3(512), kTrunkLds, s, tp);
+    else hipLaunchKernelGGL(fno_trunk_kernel<16>, dim3(tp.S * G), dim3(512), kTrunkLds, s, tp);
+    DLWP_HIP_CHECK(hipGetLastError());
+    if (tp.trace) {
+      std::vector<unsigned long long> hbuf((size_t)tp.S * G * 64);
+      DLWP_HIP_CHECK(hipStreamSynchronize(s));
+      DLWP_HIP_CHECK(hipMemcpy(hbuf.data(), trace_buf, hbuf.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(trace_path, traced ? "a" : "w")) {
+        for (int wg = 0; wg < tp.S * G; ++wg) {
+          fprintf(f, "%d %d", traced, wg);
+          for (int k = 0; k < 64 && hbuf[(size_t)wg * 64 + k]; ++k) fprintf(f, " %llu", hbuf[(size_t)wg * 64 + k]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+      ++traced;
+    }
+  }
+  st.epoch += 2u * (unsigned)p->L;
+  return DLWP_OK;
+}
+
 // one backbone step: x (channel table) -> out (+ resid)
 int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const FnoWorkspace& ws, float* out,
                  long long out_bstride, const float* resid, long long resid_bstride, hipStream_t s,
-                 KernelTimer* timer = nullptr) {
+                 TrunkState* trunk, KernelTimer* timer = nullptr) {
   const int nrow = B * p->H;
   if (timer) {  // calibration: an empty bracket measures what the event pair itself adds
     DLWP_HIP_CHECK(timer->begin(KernelTimer::EMPTY));
@@ -1477,6 +2023,14 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
   }
   float* hin = ws.h0;
   float* hout = ws.h1;
+  if (trunk && trunk->on) {
+    // all spectral layers in one launch, activation resident in registers (reported in the LAYER class)
+    if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::LAYER));
+    const int32_t rc = launch_trunk(p, ws, B, hin, hout, *trunk, s);
+    if (rc != DLWP_OK) return rc;
+    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::LAYER));
+    hin = hout;
+  } else
   for (int l = 0; l < p->L; ++l) {
     if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::MODES));
     int32_t rc = launch_modes(p->sc, ws.ybuf, ws.zbuf, p->wt[l].as<float2>(), B, s);
@@ -1570,7 +2124,10 @@ extern "C" int32_t dlwp_fno2d_forward_f32(const dlwp_fno2d_plan* plan, const flo
   ChanTable xt;
   xt.seg[0] = ChanSeg{x, plan->cin * HW, plan->cin, 0};
   for (int i = 1; i < 4; ++i) xt.seg[i] = ChanSeg{nullptr, 0, 0, 0};
-  return fno_step(plan, xt, batch, ws, y, plan->cout * HW, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
+  TrunkState trunk;
+  const int32_t rc0 = trunk_begin(plan, ws, batch, trunk, reinterpret_cast<hipStream_t>(stream));
+  if (rc0 != DLWP_OK) return rc0;
+  return fno_step(plan, xt, batch, ws, y, plan->cout * HW, nullptr, 0, reinterpret_cast<hipStream_t>(stream), &trunk);
 }
 
 static int32_t fno_rollout_impl(const dlwp_fno2d_plan* plan, const float* constants, int32_t n_const,
@@ -1600,6 +2157,11 @@ static int32_t fno_rollout_impl(const dlwp_fno2d_plan* plan, const float* consta
   if (step_end < 0) step_end = To;
   DLWP_REQUIRE(step_begin >= 0 && step_begin <= step_end && step_end <= To, DLWP_ERR_INVALID_ARGUMENT,
                "step range [%d, %d) outside [0, %d]", step_begin, step_end, To);
+  TrunkState trunk;
+  {
+    const int32_t rc0 = trunk_begin(plan, ws, batch, trunk, s);
+    if (rc0 != DLWP_OK) return rc0;
+  }
   for (int t = ctx + step_begin; t < ctx + step_end; ++t) {
     // x_t = cat(constants[:,0], prescribed[:, t-ctx:t], prognostic window)   (fno.py:49-62, :79-100)
     // prognostic window, frame f in [t-ctx, t): input frame f if f < ctx else out[:, f-ctx]
@@ -1620,7 +2182,7 @@ static int32_t fno_rollout_impl(const dlwp_fno2d_plan* plan, const float* consta
     long long resid_bs;
     if (t - 1 < ctx) { resid = prognostic + (long long)(t - 1) * n_prog * HW; resid_bs = prog_bs; }
     else { resid = out + (long long)(t - 1 - ctx) * n_prog * HW; resid_bs = out_bs; }
-    int32_t rc = fno_step(plan, xt, batch, ws, out + (long long)(t - ctx) * n_prog * HW, out_bs, resid, resid_bs, s, timer);
+    int32_t rc = fno_step(plan, xt, batch, ws, out + (long long)(t - ctx) * n_prog * HW, out_bs, resid, resid_bs, s, &trunk, timer);
     if (rc != DLWP_OK) return rc;
   }
   return DLWP_OK;
