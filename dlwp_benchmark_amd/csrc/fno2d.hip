@@ -1131,7 +1131,11 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 // as many serialized round trips to the Infinity Cache (first version of this kernel: P2 4.3 us, P3 2.9 us).
 __device__ __forceinline__ void ld4_sc1_x4(const float* base, unsigned o0, unsigned o1, unsigned o2, unsigned o3,
                                            f32x4& v0, f32x4& v1, f32x4& v2, f32x4& v3) {
+  // s_nop 4: the base may have just been restored into SGPRs by v_readlane / v_readfirstlane (SGPR spills), and a
+  // VALU-written SGPR needs 5 wait states before a VMEM instruction reads it; the compiler's hazard recognizer
+  // does not look inside inline asm (a build without this faulted with a garbage address).
   asm volatile(
+      "s_nop 4\n\t"
       "global_load_dwordx4 %0, %4, %8 sc1\n\t"
       "global_load_dwordx4 %1, %5, %8 sc1\n\t"
       "global_load_dwordx4 %2, %6, %8 sc1\n\t"
@@ -1150,17 +1154,18 @@ __device__ __forceinline__ f32x4 shfl_xor4(f32x4 v, int m) {
   return f32x4{__shfl_xor(v[0], m), __shfl_xor(v[1], m), __shfl_xor(v[2], m), __shfl_xor(v[3], m)};
 }
 
-template <int G>   // workgroups per sample = H / 8
-__global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
+// ROWS = grid rows (= waves) per workgroup, G = workgroups per sample = H / ROWS (see trunk_rows() for the choice).
+template <int ROWS, int G>
+__global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkParams p) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int W = 64, KP = 16, C = kC;
+  constexpr int W = 64, KP = 16, C = kC, NT = 64 * ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   float* s_tr = smem + wave * (C * kTrStride);            // [8][32][68]   per-wave transpose tile
-  float* s_y = smem + 8 * C * kTrStride;                  // [8][528]      Y rows of this workgroup
-  float* s_z = s_y + 8 * kSyStride;                       // [8][16][32]   Z rows of this workgroup
-  float* s_x = s_z + 8 * KP * C;                          // [8][2][64]    per-wave reduced X of two modes
-  float* s_t = s_x + 8 * 128;                             // [16][64]      T  (inverse W-DFT twiddles)
+  float* s_y = smem + ROWS * C * kTrStride;               // [ROWS][528]   Y rows of this workgroup
+  float* s_z = s_y + ROWS * kSyStride;                    // [ROWS][16][32] Z rows of this workgroup
+  float* s_x = s_z + ROWS * KP * C;                       // [ROWS][2][64] per-wave reduced X of two modes
+  float* s_t = s_x + ROWS * 128;                             // [16][64]      T  (inverse W-DFT twiddles)
   float* s_tt = s_t + KP * W;                             // [64][16]      TT (forward W-DFT twiddles)
   int* s_fail = reinterpret_cast<int*>(s_tt + W * KP);
   const int H = p.H, M1 = p.M1, M2 = p.M2, NM = M1 * M2;
@@ -1176,14 +1181,14 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
       member = i % G;
     }
   }
-  const int h = member * 8 + wave;
+  const int h = member * ROWS + wave;
   const long long HW = (long long)H * W;
   const int gs = p.sample0 + sample;                      // sample index in the activation tensors
   const long long pix = (long long)h * W + 4 * j;
   unsigned* ctr = p.ctr + sample * 32;
   if (tid == 0) *s_fail = 0;
-  for (int i = tid; i < 8 * KP * C; i += 512) s_z[i] = 0.f;   // k' slots beyond 2*M2 stay zero
-  for (int i = tid; i < KP * W; i += 512) {
+  for (int i = tid; i < ROWS * KP * C; i += NT) s_z[i] = 0.f;   // k' slots beyond 2*M2 stay zero
+  for (int i = tid; i < KP * W; i += NT) {
     s_t[i] = p.t[i];
     s_tt[i] = p.tt[i];
   }
@@ -1203,12 +1208,13 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
           *reinterpret_cast<const f32x4*>(yr + 4 * lane + 256 * u);
   }
   // loop-invariant operands
-  float a_re[4], a_im[4];   // P1: A[(r = j)][k = (hl, ri)], hl = 2s + (g >> 1), ri = g & 1
+  constexpr int KS1 = ROWS / 2;   // k-steps of P1: K = (ROWS rows) x (re, im)
+  float a_re[KS1], a_im[KS1];   // P1: A[(r = j)][k = (hl, ri)], hl = 2s + (g >> 1), ri = g & 1
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < KS1; ++s) {
     const int hl = 2 * s + (g >> 1);
     float2 e = {0.f, 0.f};
-    if (j < M1) e = p.ef[j * H + member * 8 + hl];
+    if (j < M1) e = p.ef[j * H + member * ROWS + hl];
     a_re[s] = (g & 1) ? -e.y : e.x;
     a_im[s] = (g & 1) ? e.x : e.y;
   }
@@ -1217,11 +1223,10 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
   for (int s = 0; s < 8; ++s) {
     const int r = 2 * s + (g >> 1);
     float2 e = {0.f, 0.f};
-    if (r < M1) e = p.ei[r * H + member * 8 + (j >> 1)];
+    if (r < M1 && (j >> 1) < ROWS) e = p.ei[r * H + member * ROWS + (j >> 1)];
     a3[s] = (j & 1) ? ((g & 1) ? e.x : e.y) : ((g & 1) ? -e.y : e.x);
   }
   const int ks3 = (2 * M1 + 3) / 4;
-  const float ckw = wave < M2 ? p.ck[wave] : 0.f;
   const int per = (NM + G - 1) / G;                       // modes per workgroup in P2
   const int m_lo = member * per, m_hi = (m_lo + per < NM) ? m_lo + per : NM;
   float* xp_mine = p.xpart + ((long long)sample * G + member) * NM * 64;
@@ -1249,21 +1254,21 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
     float2 wreg[2][16];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int m = m_lo + wave + 8 * u;
+      const int m = m_lo + wave + ROWS * u;
       const float2* w = p.wt[l] + ((long long)(m < m_hi ? m : 0) * C + (lane >> 5) * 16) * C + (lane & 31);
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) wreg[u][cc] = w[cc * C];
     }
-    lds_barrier();   // s_y complete (all 8 rows)
+    lds_barrier();   // s_y complete (all rows of the workgroup)
     DLWP_STAMP();
-    // ---- P1: partial H-direction DFT of the 8 own rows, columns (ky = wave, c)
-    if (wave < M2) {
+    // ---- P1: partial H-direction DFT of the own rows, columns (ky = wave, wave + ROWS, ..; c)
+    for (int ky = wave; ky < M2; ky += ROWS) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         f32x4 dre = {0.f, 0.f, 0.f, 0.f}, dim = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float b = s_y[(2 * s + (g >> 1)) * kSyStride + (2 * wave + (g & 1)) * C + 16 * nt + j];
+        for (int s = 0; s < KS1; ++s) {
+          const float b = s_y[(2 * s + (g >> 1)) * kSyStride + (2 * ky + (g & 1)) * C + 16 * nt + j];
           dre = mfma16x16x4(a_re[s], b, dre);
           dim = mfma16x16x4(a_im[s], b, dim);
         }
@@ -1271,7 +1276,7 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
         for (int r4 = 0; r4 < 4; ++r4) {
           const int r = 4 * g + r4;
           if (r < M1) {
-            float* dst = xp_mine + (long long)(wave * M1 + r) * 64 + 16 * nt + j;
+            float* dst = xp_mine + (long long)(ky * M1 + r) * 64 + 16 * nt + j;
             st_sc1(dst, dre[r4]);
             st_sc1(dst + 32, dim[r4]);
           }
@@ -1307,7 +1312,7 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
     // ---- P2: channel mixing of this workgroup's share of the modes, two modes per pass.
     // lane (q4 = lane >> 4, quad = lane & 15) fetches floats 4 quad..4 quad+3 of the partials q4, q4+4, ...
     for (int up = 0; up < 2; ++up) {
-      const int ma = m_lo + wave + 16 * up, mb = ma + 8;
+      const int ma = m_lo + wave + 2 * ROWS * up, mb = ma + ROWS;
       if (ma >= m_hi) break;
       const bool has_b = mb < m_hi;
       const int q4 = lane >> 4, quad = lane & 15;
@@ -1360,8 +1365,9 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
     target += (unsigned)G;
     trunk_group_barrier(ctr, target, s_fail);
     DLWP_STAMP();
-    // ---- P3: inverse H-direction DFT for the 8 own rows, columns (ky = wave, o) -> s_z
-    if (wave < M2) {
+    // ---- P3: inverse H-direction DFT for the own rows, columns (ky = wave, wave + ROWS, ..; o) -> s_z
+    for (int ky = wave; ky < M2; ky += ROWS) {
+      const float ckw = p.ck[ky];
       // O[ky = wave][r][re/im][o]: M1 * 64 floats, fetched with coalesced 16-byte loads into the (idle) transpose tile
       {
         const int nflt = M1 * 64;
@@ -1369,7 +1375,7 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int f = 4 * lane + 256 * i;
-          o[i] = (unsigned)((wave * nflt + (f < nflt ? f : 0)) * 4);
+          o[i] = (unsigned)((ky * nflt + (f < nflt ? f : 0)) * 4);
         }
         f32x4 v0, v1, v2, v3;
         ld4_sc1_x4(ob, o[0], o[1], o[2], o[3], v0, v1, v2, v3);
@@ -1392,8 +1398,9 @@ __global__ __launch_bounds__(512) void fno_trunk_kernel(const TrunkParams p) {
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4)
-          s_z[(2 * g + (r4 >> 1)) * (KP * C) + (2 * wave + (r4 & 1)) * C + 16 * nt + j] = d[r4] * ckw;
+          if (2 * g + (r4 >> 1) < ROWS) s_z[(2 * g + (r4 >> 1)) * (KP * C) + (2 * ky + (r4 & 1)) * C + 16 * nt + j] = d[r4] * ckw;
       }
+      wave_lds_fence();   // the transpose tile is reused for the next ky
     }
     lds_barrier();
     DLWP_STAMP();
@@ -1853,7 +1860,7 @@ FnoWorkspace carve(const dlwp_fno2d_plan* p, int B, void* base) {
   w.h1 = reinterpret_cast<float*>(c + act);
   w.ybuf = reinterpret_cast<float*>(c + 2 * act);
   w.zbuf = reinterpret_cast<float*>(c + 2 * act + yz);
-  const int G = (p->H + 7) / 8;
+  const int G = (p->H + 3) / 4;   // most workgroups per sample the fused trunk uses
   const size_t nm = (size_t)p->sc.M1 * p->sc.M2 * 64 * 4;
   const size_t xp = align_up((size_t)B * G * nm, 256), ob = align_up((size_t)B * nm, 256);
   const size_t ct = align_up((size_t)B * kCtrStrideBytes, 256);
@@ -1902,14 +1909,35 @@ bool trunk_enabled() {
   }();
   return on;
 }
-constexpr size_t kTrunkLds = ((size_t)8 * kC * kTrStride + 8 * kSyStride + 8 * 16 * kC + 8 * 128 + 2 * 16 * 64 + 4) * sizeof(float);
+constexpr size_t trunk_lds(int rows) {
+  return ((size_t)rows * kC * kTrStride + rows * kSyStride + rows * 16 * kC + rows * 128 + 2 * 16 * 64 + 4) * sizeof(float);
+}
+// rows (= waves) per workgroup.  8 = one workgroup per CU (default).  4 puts two workgroups on a CU (2 x 61 KB of
+// LDS, 2 x 4 waves x 256 VGPRs) so that one can compute rows while the other sits in a group barrier -- measured
+// SLOWER at the headline size (68 vs 51 us per launch: twice the partials to publish and sum, two ky columns per
+// wave in P1/P3); kept for grids whose height is not a multiple of 8 and selectable with DLWP_TRUNK_ROWS=4.
+int trunk_rows(const dlwp_fno2d_plan* p) {
+  static const int forced = [] {
+    const char* e = getenv("DLWP_TRUNK_ROWS");
+    return e ? atoi(e) : 0;
+  }();
+  for (int rows : {8, 4}) {
+    if (forced && rows != forced) continue;
+    if (p->H % rows) continue;
+    const int G = p->H / rows;
+    if (G != 4 && G != 8 && G != 16 && G != 32) continue;          // instantiated group sizes
+    if (rows == 4 && G == 4) continue;
+    if (rows == 8 && G == 32) continue;
+    if ((p->sc.M1 * p->sc.M2 + G - 1) / G > 4 * rows) continue;    // at most 4 modes per wave in P2
+    if (G > device_cu_count() * (8 / rows)) continue;              // a sample's group must be resident at once
+    return rows;
+  }
+  return 0;
+}
 bool trunk_eligible(const dlwp_fno2d_plan* p) {
   if (!trunk_enabled() || !use_bf16x6()) return false;
-  const int G = p->H / 8;
-  if (p->W != 64 || p->H % 8 != 0 || p->sc.KP != 16 || p->sc.M1 > 16 || p->L > kTrunkMaxLayers) return false;
-  if (G != 4 && G != 8 && G != 16) return false;              // instantiated group sizes (H = 32, 64, 128)
-  if ((p->sc.M1 * p->sc.M2 + G - 1) / G > 32) return false;   // at most 4 modes per wave in P2
-  return G <= device_cu_count();   // a sample's group must be resident at once (one workgroup per CU)
+  if (p->W != 64 || p->sc.KP != 16 || p->sc.M1 > 16 || p->L > kTrunkMaxLayers) return false;
+  return trunk_rows(p) != 0;
 }
 struct TrunkState {
   bool on = false;
@@ -1921,15 +1949,22 @@ int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, Tru
   if (st.on) DLWP_HIP_CHECK(hipMemsetAsync(ws.ctr, 0, (size_t)B * kCtrStrideBytes, s));
   return DLWP_OK;
 }
+template <int ROWS, int G>
+hipError_t trunk_launch_one(const TrunkParams& tp, hipStream_t s) {
+  constexpr size_t lds = trunk_lds(ROWS);
+  hipError_t e = allow_lds(fno_trunk_kernel<ROWS, G>, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((fno_trunk_kernel<ROWS, G>), dim3(tp.S * G), dim3(64 * ROWS), lds, s, tp);
+  return hipGetLastError();
+}
 int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, const float* hin, float* hout,
                      TrunkState& st, hipStream_t s) {
-  const int G = p->H / 8;
-  int per_launch = device_cu_count() / G;
+  const int rows = trunk_rows(p);
+  DLWP_REQUIRE(rows > 0, DLWP_ERR_UNSUPPORTED, "fused trunk not available for this plan");
+  const int G = p->H / rows;
+  int per_launch = device_cu_count() * (8 / rows) / G;
   if (per_launch >= 8) per_launch &= ~7;   // keeps the same-XCD group mapping
-  DLWP_REQUIRE(per_launch > 0, DLWP_ERR_UNSUPPORTED, "a sample needs %d workgroups, more than the device has CUs", G);
-  DLWP_HIP_CHECK(allow_lds(fno_trunk_kernel<4>, kTrunkLds));
-  DLWP_HIP_CHECK(allow_lds(fno_trunk_kernel<8>, kTrunkLds));
-  DLWP_HIP_CHECK(allow_lds(fno_trunk_kernel<16>, kTrunkLds));
+  DLWP_REQUIRE(per_launch > 0, DLWP_ERR_UNSUPPORTED, "a sample needs %d workgroups, more than fit the device", G);
   const size_t nm = (size_t)p->sc.M1 * p->sc.M2 * 64;
   for (int s0 = 0; s0 < B; s0 += per_launch) {
     TrunkParams tp;
@@ -1956,10 +1991,14 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
       DLWP_HIP_CHECK(hipMemsetAsync(trace_buf, 0, (size_t)1024 * 64 * 8, s));
       if (tp.S * G <= 1024) tp.trace = trace_buf;
     }
-    if (G == 4) hipLaunchKernelGGL(fno_trunk_kernel<4>, dim3(tp.S * G), dim3(512), kTrunkLds, s, tp);
-    else if (G == 8) hipLaunchKernelGGL(fno_trunk_kernel<8>, dim3(tp.S * G), dim3(512), kTrunkLds, s, tp);
-    else hipLaunchKernelGGL(fno_trunk_kernel<16>, dim3(tp.S * G), dim3(512), kTrunkLds, s, tp);
-    DLWP_HIP_CHECK(hipGetLastError());
+    hipError_t le = hipErrorInvalidValue;
+    if (rows == 8 && G == 4) le = trunk_launch_one<8, 4>(tp, s);
+    else if (rows == 8 && G == 8) le = trunk_launch_one<8, 8>(tp, s);
+    else if (rows == 8 && G == 16) le = trunk_launch_one<8, 16>(tp, s);
+    else if (rows == 4 && G == 8) le = trunk_launch_one<4, 8>(tp, s);
+    else if (rows == 4 && G == 16) le = trunk_launch_one<4, 16>(tp, s);
+    else if (rows == 4 && G == 32) le = trunk_launch_one<4, 32>(tp, s);
+    DLWP_HIP_CHECK(le);
     if (tp.trace) {
       std::vector<unsigned long long> hbuf((size_t)tp.S * G * 64);
       DLWP_HIP_CHECK(hipStreamSynchronize(s));
