@@ -96,7 +96,10 @@ class FNO2DModule(HipBackbone):
             self._plan = None
 
     def __del__(self):
-        self._destroy_plan()
+        try:  # at interpreter shutdown torch internals may already be torn down
+            self._destroy_plan()
+        except Exception:
+            pass
 
     def _get_plan(self, h: int, w: int, device):
         key = (h, w, str(device), self._param_key())

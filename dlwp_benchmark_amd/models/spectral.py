@@ -34,7 +34,10 @@ class SpectralConv2d(nn.Module):
             self._plan = None
 
     def __del__(self):
-        self._destroy_plan()
+        try:  # at interpreter shutdown torch internals may already be torn down
+            self._destroy_plan()
+        except Exception:
+            pass
 
     def _get_plan(self, h, w, device):
         key = (h, w, str(device), self.weights1._version, self.weights1.data_ptr(), self.weights2._version,
