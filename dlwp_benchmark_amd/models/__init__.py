@@ -10,8 +10,8 @@ from .fno import FNO2DModule
 from .fourcastnet import AFNONet, FourCastNet
 from .pangu import PanguWeather
 from .spectral import SpectralConv2d
-from .swin import SwinTransformer
+from .swin import SwinTransformer, SwinTransformerHPX
 from .unet import ConvLSTM, HEALPixLayer, HEALPixPadding, UNet, UNetHPX
 
-__all__ = ["FNO2DModule", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "UNet",
+__all__ = ["FNO2DModule", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "SwinTransformerHPX", "UNet",
            "UNetHPX", "ConvLSTM", "HEALPixPadding", "HEALPixLayer"]

@@ -147,8 +147,11 @@ class SwinTransformer(HipBackbone):
                  drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer="nn.LayerNorm", ape=False,
                  patch_norm=True, frozen_stages=-1, use_checkpoint=False, mesh="equirectangular", **kwargs):
         super().__init__()
-        if mesh != "equirectangular":
-            raise NotImplementedError("HEALPix variant is a 'next' row (SURVEY.md 8f f3)")
+        if mesh not in ("equirectangular", "healpix"):
+            raise ValueError(f"unknown mesh {mesh!r}")
+        # mesh == "healpix" (SwinTransformerHPX): the reference takes the same code path whenever the map divides by
+        # patch and window (swin_transformer.py:220-251), and crashes otherwise (:451 `hpx_pad` does not exist)
+        self.mesh = mesh
         if ape:
             raise NotImplementedError("absolute position embedding (ape=True) is not used by any reference config")
         self.context_size = int(context_size)
@@ -217,3 +220,38 @@ class SwinTransformer(HipBackbone):
             out = torch.empty(b, t - self.context_size, cg, h, w, device=prognostic.device, dtype=torch.float32)
             self.rollout_into(out, constants, prescribed, prognostic)
         return out
+
+
+class SwinTransformerHPX(SwinTransformer):
+    """reference swin_transformer.py:745-878: Swin on the HEALPix mesh.  The 12 faces [.., 12, h, w] are laid out as
+    a 3 x 4 rectangle (north / equatorial / south bands, `_faces2rect` :826-834), the equirectangular backbone runs
+    on that [3h, 4w] map (`img_height`, `img_width` are the RECTANGLE's size) and the result is cut back into faces
+    (`_reshape_output` :867-878).  The layout change commutes with the residual add of the rollout, so it is done once
+    on the inputs and once on the trajectory instead of every step."""
+
+    def __init__(self, *args, mesh="healpix", **kwargs):
+        super().__init__(*args, mesh="healpix", **kwargs)
+
+    @staticmethod
+    def faces_to_rect(t: torch.Tensor) -> torch.Tensor:
+        """[B, T, C, 12, h, w] -> [B, T, C, 3h, 4w]"""
+        b, tt, c, f, h, w = t.shape
+        return t.reshape(b, tt, c, 3, 4, h, w).permute(0, 1, 2, 3, 5, 4, 6).reshape(b, tt, c, 3 * h, 4 * w)
+
+    @staticmethod
+    def rect_to_faces(t: torch.Tensor) -> torch.Tensor:
+        """[B, T, C, 3h, 4w] -> [B, T, C, 12, h, w]"""
+        b, tt, c, hh, ww = t.shape
+        h, w = hh // 3, ww // 4
+        return t.reshape(b, tt, c, 3, h, 4, w).permute(0, 1, 2, 3, 5, 4, 6).reshape(b, tt, c, 12, h, w)
+
+    def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        for name, t in (("constants", constants), ("prescribed", prescribed), ("prognostic", prognostic)):
+            if t is not None and (t.dim() != 6 or t.shape[3] != 12):
+                raise _lib.DlwpError(f"{name}: expected [B, T, C, 12, H, W], got {tuple(t.shape)}")
+        if prognostic is None:
+            raise _lib.DlwpError("prognostic is required")
+        rect = lambda t: self.faces_to_rect(t).contiguous() if t is not None else None
+        out = super().forward(constants=rect(constants), prescribed=rect(prescribed), prognostic=rect(prognostic))
+        return self.rect_to_faces(out).contiguous()

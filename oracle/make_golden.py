@@ -181,6 +181,15 @@ HPX_MODEL_CASES = {
 }
 
 
+HPX_SWIN_CASES = {
+    # img_height / img_width are the size of the 3 x 4 face rectangle (nside 8 -> 24 x 32)
+    "swinhpx_e16_n8": (dict(constant_channels=2, prescribed_channels=1, prognostic_channels=3, context_size=1,
+                            img_height=24, img_width=32, patch_size=2, embed_dim=16, depths=[2, 2], num_heads=[2, 4],
+                            mlp_ratio=2, qkv_bias=True, drop_path_rate=0.1, norm_layer="nn.LayerNorm", patch_norm=True),
+                       (2, 4), (8, 8)),
+}
+
+
 def hpx_inputs(tag, cfg, batch, frames, hw):
     h, w = hw
     cc, cp, cg = cfg["constant_channels"], cfg["prescribed_channels"], cfg["prognostic_channels"]
@@ -201,6 +210,17 @@ def gen_hpx(ref):
         _save(f"healpix_pad_{tag}", y=y.numpy(), sha=np.array(tensor_sha(x)))
     for tag, (cfg, (batch, frames), hw) in HPX_MODEL_CASES.items():
         m = ref["unet"].UNetHPX(**cfg)
+        m.eval()
+        sha = W.fill_state_dict(m, gain=1.0)
+        constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
+        with torch.no_grad():
+            y = m(constants=constants, prescribed=prescribed, prognostic=prognostic)
+        spec = [(k, list(v.shape)) for k, v in m.named_parameters()]
+        full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]
+        _save(f"model_{tag}", y=y.numpy().astype(np.float32), sha=np.array(sha), param_spec=np.array(json.dumps(spec)),
+              state_spec=np.array(json.dumps(full)))
+    for tag, (cfg, (batch, frames), hw) in HPX_SWIN_CASES.items():
+        m = ref["swin"].SwinTransformerHPX(**cfg)
         m.eval()
         sha = W.fill_state_dict(m, gain=1.0)
         constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
