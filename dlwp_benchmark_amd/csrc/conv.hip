@@ -4,7 +4,8 @@
 // (reference utils/utils.py:11-26; models/unet/unet.py:456-470, :512-525; models/convlstm/convlstm.py:47-55,
 // :148-157) -- and, for the skip connections and the ConvLSTM cell, the preceding `torch.cat`
 // (unet.py:553; convlstm.py:94): the input may be given as TWO channel segments.
-// Direct convolution: one workgroup = one 8x32 output tile of one sample; the (8+2)x(32+2) input halo
+// Direct convolution: one workgroup = one output tile (8x32, 16x16 or 8x8 by map width) of one sample and one
+// 16-channel output chunk; the (TH+2)x(TW+2) input halo
 // tile of a chunk of input channels is staged in LDS with the cylinder rule applied at load time
 // (longitude wraps, latitude pads with zeros), every thread owns one pixel and accumulates a chunk of
 // output channels with weights broadcast from LDS; bias + activation fused in the epilogue.
@@ -25,7 +26,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-constexpr int TH = 8, TW = 32, CI_CHUNK = 8, CO_CHUNK = 16;
+constexpr int CI_CHUNK = 8, CO_CHUNK = 16;
 
 struct Params {
   const float* x0; int c0;   // first input segment [B][c0][H][W]
@@ -40,7 +41,11 @@ struct Params {
   const int2* hpx;
 };
 
-__global__ __launch_bounds__(256) void conv3x3_cyl_kernel(const Params p) {
+// TH x TW output tile per workgroup (TH*TW threads); blockIdx.z selects the 16-channel output chunk, so the deep,
+// low-resolution layers of a U-Net (8x8 maps with 64 channels) still spread over enough workgroups.
+template <int TH, int TW>
+__global__ __launch_bounds__(TH * TW) void conv3x3_cyl_kernel(const Params p) {
+  constexpr int NT = TH * TW;
   __shared__ float s_in[CI_CHUNK][TH + 2][TW + 2];
   __shared__ float s_w[CO_CHUNK][CI_CHUNK][9];
   const int tid = threadIdx.x;
@@ -51,13 +56,14 @@ __global__ __launch_bounds__(256) void conv3x3_cyl_kernel(const Params p) {
   const int cin = p.c0 + p.c1;
   const int ow = w0 + tx, oh = h0 + ty;
   const long long HW = (long long)p.H * p.W;
-  for (int co0 = 0; co0 < p.Cout; co0 += CO_CHUNK) {
+  {
+    const int co0 = blockIdx.z * CO_CHUNK;
     float acc[CO_CHUNK];
 #pragma unroll
     for (int k = 0; k < CO_CHUNK; ++k) acc[k] = 0.f;
     for (int ci0 = 0; ci0 < cin; ci0 += CI_CHUNK) {
       __syncthreads();
-      for (int i = tid; i < CI_CHUNK * (TH + 2) * (TW + 2); i += 256) {
+      for (int i = tid; i < CI_CHUNK * (TH + 2) * (TW + 2); i += NT) {
         const int ci = i / ((TH + 2) * (TW + 2));
         const int rem = i % ((TH + 2) * (TW + 2));
         const int r = rem / (TW + 2), cc = rem % (TW + 2);
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void conv3x3_cyl_kernel(const Params p) {
         }
         (&s_in[0][0][0])[i] = v;
       }
-      for (int i = tid; i < CO_CHUNK * CI_CHUNK * 9; i += 256) {
+      for (int i = tid; i < CO_CHUNK * CI_CHUNK * 9; i += NT) {
         const int k = i / (CI_CHUNK * 9), rem = i % (CI_CHUNK * 9);
         const int ci = rem / 9, t = rem % 9;
         const int co = co0 + k, c = ci0 + ci;
@@ -174,6 +180,17 @@ __global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __rest
 
 using namespace dlwp;
 
+static void launch_conv3x3(const conv::Params& p, hipStream_t s) {
+  const int zc = (p.Cout + conv::CO_CHUNK - 1) / conv::CO_CHUNK;
+  auto tiles = [&](int th, int tw) { return ((p.W + tw - 1) / tw) * ((p.H + th - 1) / th); };
+  if (p.W >= 32)
+    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<8, 32>), dim3(tiles(8, 32), p.B, zc), dim3(256), 0, s, p);
+  else if (p.W >= 16)
+    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<16, 16>), dim3(tiles(16, 16), p.B, zc), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<8, 8>), dim3(tiles(8, 8), p.B, zc), dim3(64), 0, s, p);
+}
+
 extern "C" int32_t dlwp_conv3x3_cyl_f32(const float* x0, int32_t c0, const float* x1, int32_t c1, const float* weight,
                                         const float* bias, float* y, int32_t batch, int32_t H, int32_t W, int32_t cout,
                                         int32_t act, void* stream) {
@@ -184,8 +201,8 @@ extern "C" int32_t dlwp_conv3x3_cyl_f32(const float* x0, int32_t c0, const float
   conv::Params p;
   p.x0 = x0; p.c0 = c0; p.x1 = x1; p.c1 = c1; p.w = weight; p.bias = bias; p.y = y;
   p.B = batch; p.H = H; p.W = W; p.Cout = cout; p.act = act; p.hpx = nullptr;
-  const int tiles = ((W + conv::TW - 1) / conv::TW) * ((H + conv::TH - 1) / conv::TH);
-  hipLaunchKernelGGL(conv::conv3x3_cyl_kernel, dim3(tiles, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DLWP_REQUIRE(batch <= 65535, DLWP_ERR_UNSUPPORTED, "batch %d exceeds the grid's y dimension", batch);
+  launch_conv3x3(p, reinterpret_cast<hipStream_t>(stream));
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
@@ -202,8 +219,8 @@ extern "C" int32_t dlwp_conv3x3_hpx_f32(const float* x0, int32_t c0, const float
   conv::Params p;
   p.x0 = x0; p.c0 = c0; p.x1 = x1; p.c1 = c1; p.w = weight; p.bias = bias; p.y = y;
   p.B = n_faces; p.H = H; p.W = W; p.Cout = cout; p.act = act; p.hpx = reinterpret_cast<const int2*>(ring_table);
-  const int tiles = ((W + conv::TW - 1) / conv::TW) * ((H + conv::TH - 1) / conv::TH);
-  hipLaunchKernelGGL(conv::conv3x3_cyl_kernel, dim3(tiles, n_faces), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DLWP_REQUIRE(n_faces <= 65535, DLWP_ERR_UNSUPPORTED, "n_faces %d exceeds the grid's y dimension", n_faces);
+  launch_conv3x3(p, reinterpret_cast<hipStream_t>(stream));
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
