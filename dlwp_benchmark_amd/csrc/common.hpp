@@ -50,6 +50,14 @@ struct DevBuf {
   ~DevBuf() {
     if (p) (void)hipFree(p);
   }
+  hipError_t alloc(size_t n) {
+    if (p) {
+      (void)hipFree(p);
+      p = nullptr;
+    }
+    bytes = n;
+    return hipMalloc(&p, n ? n : 4);
+  }
   hipError_t upload(const void* host, size_t n, hipStream_t s) {
     if (p) {
       (void)hipFree(p);

@@ -1467,6 +1467,22 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
       *reinterpret_cast<f32x4*>(p.y + ((long long)gs * C + 16 * ot + 4 * g + r) * HW + pix) = vv[ot][r];
 }
 
+// Spectral weights [Ci][Co][R][K][2] (reference / PyTorch layout, device) -> the kernels' [K][R][Ci'][Co'] float2.
+// adjoint: the conjugate transpose (Ci' = Co, Co' = Ci), i.e. the weights of the backward-data convolution.
+__global__ __launch_bounds__(256) void pack_spectral_kernel(const float2* __restrict__ src, float2* __restrict__ dst,
+                                                            int Ci, int Co, int R, int K, int adjoint) {
+  const long long total = (long long)Ci * Co * R * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ky = (int)(i % K);
+    const int r = (int)((i / K) % R);
+    const int o = (int)((i / ((long long)K * R)) % Co);
+    const int c = (int)(i / ((long long)K * R * Co));
+    const float2 v = src[i];
+    if (adjoint) dst[(((long long)ky * R + r) * Co + o) * Ci + c] = float2{v.x, -v.y};
+    else dst[(((long long)ky * R + r) * Ci + c) * Co + o] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -2308,6 +2324,48 @@ extern "C" int32_t dlwp_spectral_conv2d_plan_create(dlwp_spectral_plan** out, in
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) { delete p; return fail(DLWP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
   *out = p;
+  return DLWP_OK;
+}
+
+// General mode-truncated spectral convolution (explicit kept rows and transform scales) with weights set from the
+// DEVICE: what a training step needs (weights change every step; the backward-data pass is the same operator with
+// rows_in/rows_out swapped and conjugate-transposed weights).
+extern "C" int32_t dlwp_spectral_conv2d_plan_create_ex(dlwp_spectral_plan** out, int32_t ci, int32_t co, int32_t H,
+                                                       int32_t W, int32_t n_rows, int32_t n_cols, const int32_t* rows_in,
+                                                       const int32_t* rows_out, float fwd_scale, float inv_scale,
+                                                       void* stream) {
+  DLWP_REQUIRE(out && rows_in && rows_out, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  DLWP_REQUIRE(ci == kC && co == kC, DLWP_ERR_UNSUPPORTED, "SpectralConv2d kernels are specialised for %d channels", kC);
+  DLWP_REQUIRE(W > 0 && W % 64 == 0 && H > 0, DLWP_ERR_UNSUPPORTED, "width %d must be a positive multiple of 64", W);
+  DLWP_REQUIRE(n_rows >= 1 && n_rows <= H && n_cols >= 1 && n_cols <= W / 2 + 1, DLWP_ERR_INVALID_ARGUMENT, "bad mode counts");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto* p = new dlwp_spectral_plan();
+  p->ci = ci; p->co = co;
+  int32_t rc = p->sc.build(H, W, n_rows, n_cols, rows_in, rows_out, fwd_scale, inv_scale, s);
+  if (rc != DLWP_OK) { delete p; return rc; }
+  std::vector<float> zb(kC, 0.f);
+  hipError_t e = p->wt.alloc((size_t)n_cols * n_rows * ci * co * 2 * sizeof(float));
+  if (e == hipSuccess) e = hipMemsetAsync(p->wt.p, 0, p->wt.bytes, s);
+  if (e == hipSuccess) e = p->zero_bias.upload(zb.data(), zb.size() * 4, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { delete p; return fail(DLWP_ERR_HIP, "plan allocation failed: %s", hipGetErrorString(e)); }
+  *out = p;
+  return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_spectral_conv2d_set_weights_dev(dlwp_spectral_plan* plan, const float* weights_dev,
+                                                        int32_t adjoint, void* stream) {
+  DLWP_REQUIRE(plan && weights_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  const int R = plan->sc.M1, K = plan->sc.M2;
+  const long long total = (long long)plan->ci * plan->co * R * K;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  // weights_dev is [Ci][Co][R][K][2] of the FORWARD operator in both cases
+  hipLaunchKernelGGL(pack_spectral_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float2*>(weights_dev), plan->wt.as<float2>(), plan->ci, plan->co, R, K,
+                     adjoint ? 1 : 0);
+  DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
 

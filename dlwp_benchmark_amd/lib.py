@@ -59,6 +59,9 @@ SIGNATURES = {
                                                   POINTER(ctypes.c_double), c_int32_p]),
     "dlwp_spectral_conv2d_plan_create": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32,
                                                    c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "dlwp_spectral_conv2d_plan_create_ex": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                      c_int32, c_void_p, c_void_p, c_float, c_float, c_void_p]),
+    "dlwp_spectral_conv2d_set_weights_dev": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "dlwp_spectral_conv2d_plan_destroy": (c_int32, [c_void_p]),
     "dlwp_spectral_conv2d_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
     "dlwp_window_attn_f32": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),

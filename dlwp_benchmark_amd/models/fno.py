@@ -198,8 +198,60 @@ class FNO2DModule(HipBackbone):
                 _lib.stream_ptr(), step_begin, step_end), "dlwp_fno2d_rollout_range_f32")
         return out
 
+    # ------------------------------------------------------------------ training (first slice)
+    def _train_step(self, x_t: torch.Tensor) -> torch.Tensor:
+        """One differentiable backbone step: spectral convolutions through the HIP kernels (forward and
+        backward-data, dlwp_benchmark_amd/training.py), the pointwise parts through torch ops."""
+        import torch.nn.functional as F
+
+        from .. import training as T
+
+        f = self.fno
+        _, _, h, w = x_t.shape
+        key = (h, w, str(x_t.device))
+        if getattr(self, "_train_op_key", None) != key:
+            rows_in, rows_out = kept_rows(h, f.n_modes[0])
+            n_cols = min(w // 2 + 1, f.n_modes[1] // 2 + 1)
+            self._train_op = T.SpectralOperator(f.lifting.fcs[1].out_channels, h, w, rows_in, rows_out, n_cols,
+                                                1.0 / float(h * w), 1.0, x_t.device)
+            self._train_op_key = key
+        op = self._train_op
+        hid = f.lifting.fcs[1](F.gelu(f.lifting.fcs[0](x_t)))
+        n_layers = len(f.fno_blocks.fno_skips)
+        for l in range(n_layers):
+            wl = torch.view_as_real(f.fno_blocks.convs.weight[l].tensor)[:, :, :len(op.rows_in), :op.n_cols]
+            hid = T.spectral_conv(hid, wl, op) + f.fno_blocks.convs.bias[l] + f.fno_blocks.fno_skips[l](hid)
+            if l < n_layers - 1:
+                hid = F.gelu(hid)
+        return f.projection.fcs[1](F.gelu(f.projection.fcs[0](hid)))
+
+    def _forward_train(self, constants, prescribed, prognostic):
+        """fno.py:79-106 with autograd alive (the loop the reference trains through, train.py:263-271)."""
+        ctx = self.context_size
+        outs = []
+        for t in range(ctx, prognostic.shape[1]):
+            t0 = max(0, t - ctx)
+            if t == ctx:
+                prog_t = prognostic[:, t0:t]
+                presc_t = prescribed[:, t0:t] if prescribed is not None else None
+            else:
+                prog_t = torch.cat([prognostic[:, t0:ctx], torch.stack(outs, dim=1)[:, -ctx:]], dim=1)
+                presc_t = prescribed[:, t - ctx:t] if prescribed is not None else None
+            parts = []
+            if constants is not None:
+                parts.append(constants[:, 0])
+            if presc_t is not None:
+                parts.append(presc_t.flatten(1, 2))
+            parts.append(prog_t.flatten(1, 2))
+            outs.append(prog_t[:, -1] + self._train_step(torch.cat(parts, dim=1).contiguous()))
+        return torch.stack(outs, dim=1)
+
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            for name, t in (("constants", constants), ("prescribed", prescribed), ("prognostic", prognostic)):
+                _lib.require_cuda_tensor(t, name)
+            return self._forward_train(constants, prescribed, prognostic)
         constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
         with torch.no_grad():
             b, t, cg, h, w = prognostic.shape

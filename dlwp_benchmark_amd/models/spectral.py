@@ -56,9 +56,29 @@ class SpectralConv2d(nn.Module):
         self._plan, self._plan_key = plan, key
         return plan
 
-    @torch.no_grad()
+    def _forward_train(self, x):
+        """Differentiable path: HIP forward and backward-data, rocFFT + einsum weight gradient."""
+        from .. import training as T
+
+        _, _, h, w = x.shape
+        key = (h, w, str(x.device))
+        if getattr(self, "_train_op_key", None) != key:
+            rows, _ = T.pde_arena_rows(h, self.modes1)
+            self._train_op = T.SpectralOperator(self.in_channels, h, w, rows, rows, self.modes2, 1.0, 1.0 / float(h * w),
+                                                x.device)
+            self._train_op_key = key
+        return T.spectral_conv(x, torch.cat([self.weights1, self.weights2], dim=2), self._train_op)
+
     def forward(self, x, x_dim=None, y_dim=None):
         _lib.require_cuda_tensor(x, "x")
+        if torch.is_grad_enabled() and (x.requires_grad or self.weights1.requires_grad and self.training):
+            if self.in_channels != self.out_channels:
+                raise _lib.DlwpError("training path needs in_channels == out_channels (== 32)")
+            return self._forward_train(x)
+        with torch.no_grad():
+            return self._forward_infer(x)
+
+    def _forward_infer(self, x):
         x = x.contiguous()
         b, c, h, w = x.shape
         if c != self.in_channels:

@@ -143,6 +143,19 @@ int32_t dlwp_spectral_conv2d_plan_create(dlwp_spectral_plan** plan, int32_t in_c
                                          const float* weights1_host, /* [Ci,Co,m1,m2,2] */
                                          const float* weights2_host, /* [Ci,Co,m1,m2,2] */
                                          void* stream);
+/* The same operator with explicit kept rows and transform scales (SpectralCore of the FNO layers: row r of the
+ * weights reads un-shifted rfft row rows_in[r] and writes row rows_out[r]; x_hat is scaled by fwd_scale, the inverse
+ * by inv_scale) and weights that live on the DEVICE -- what a training step needs (reference
+ * scripts/train.py:263-271 `loss.backward()` through models/unet/unet.py:46-69 / neuralop SpectralConv).
+ * dlwp_spectral_conv2d_set_weights_dev packs weights_dev [Ci, Co, n_rows, n_cols, 2] (PyTorch layout, forward
+ * operator) into the plan on `stream`; with adjoint != 0 it packs the conjugate transpose, which makes
+ * dlwp_spectral_conv2d_f32 the BACKWARD-DATA pass (create that plan with rows_in and rows_out swapped). */
+int32_t dlwp_spectral_conv2d_plan_create_ex(dlwp_spectral_plan** plan, int32_t in_channels, int32_t out_channels,
+                                            int32_t height, int32_t width, int32_t n_rows, int32_t n_cols,
+                                            const int32_t* rows_in, const int32_t* rows_out, float fwd_scale,
+                                            float inv_scale, void* stream);
+int32_t dlwp_spectral_conv2d_set_weights_dev(dlwp_spectral_plan* plan, const float* weights_dev, int32_t adjoint,
+                                             void* stream);
 int32_t dlwp_spectral_conv2d_plan_destroy(dlwp_spectral_plan* plan);
 size_t dlwp_spectral_conv2d_workspace_bytes(const dlwp_spectral_plan* plan, int32_t batch);
 int32_t dlwp_spectral_conv2d_f32(const dlwp_spectral_plan* plan, const float* x_dev, float* y_dev,

@@ -62,6 +62,15 @@ def gen_spectral(ref):
             mod.weights2.copy_(w2)
             y = mod(x)
         _save(f"spectral_conv2d_{tag}", y=y.numpy(), sha=np.array(tensor_sha(x, w1, w2)))
+        if tag == "c32_64x64_m12":
+            continue   # gradient fixtures only for the two smaller cases (size)
+        # gradients of L = sum(y * r) through the REAL class (training row f4): dL/dx, dL/dweights1, dL/dweights2
+        r = W.normal(f"golden/spectral/{tag}/r", tuple(y.shape), 1.0)
+        xg = x.clone().requires_grad_(True)
+        mod.zero_grad()
+        (mod(xg) * r).sum().backward()
+        _save(f"spectral_conv2d_grad_{tag}", gx=xg.grad.numpy(), gw1=mod.weights1.grad.numpy(),
+              gw2=mod.weights2.grad.numpy(), sha=np.array(tensor_sha(x, w1, w2, r)))
 
 
 # ------------------------------------------------------------------------------------------
