@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8, help="samples of the bounded CPU-baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-chunks", type=int, default=4)
+    ap.add_argument("--collect", choices=["metrics", "gather", "none"], default="metrics",
+                    help="what leaves a rank per rollout: per-lead-time RMSE sums reduced on the device and all-reduced "
+                         "(default; SURVEY.md 8e/8f-f1), the whole trajectory (one chunked RCCL all-gather), or nothing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,10 +162,21 @@ def main():
     model, sha = build_model(device)
     _, _, prog_cpu = navier_stokes(B, K_roll + 1, H, W, seed=1234 + rank)
     prog = prog_cpu.to(device)
-    runner = ShardedRollout(model, world_size=world, rank=rank, chunks=args.gather_chunks)
+    runner = ShardedRollout(model, world_size=world, rank=rank, chunks=args.gather_chunks,
+                            gather=(args.collect == "gather"))
+    # evaluation scores of the rollout against the frames the synthetic solver produced (uniform weights on the
+    # periodic box): reduced on the device, all-reduced across ranks -- [4, K, C] doubles instead of trajectories
+    from dlwp_benchmark_amd.metrics import RolloutMetrics
+
+    scorer = RolloutMetrics(torch.zeros(H))
+    target = prog[:, model.context_size:].contiguous()
+    scores = {}
 
     def step():
-        return runner(prognostic=prog)
+        out = runner(prognostic=prog)
+        if args.collect == "metrics":
+            scores["last"] = scorer(out, target, world_size=world)   # sums kernel (+ all-reduce when world > 1)
+        return out
 
     for _ in range(args.warmup):
         out = step()
@@ -199,7 +213,11 @@ def main():
         "config": {
             "workload": "FNO2d modes=12 hidden=32 lift/proj=256 layers=4, Navier-Stokes 64x64, 20-step rollout, fp32 (BASELINE configs[1])",
             "batch_per_gpu": B, "global_batch": B * world, "grid": [H, W], "rollout_steps": K_roll,
-            "parallelism": f"batch-shard x{world} + all-gather" if world > 1 else "single GPU",
+            "parallelism": (f"batch-shard x{world}, " + {"metrics": "all-reduce of on-device RMSE sums",
+                                                          "gather": "chunked all-gather of trajectories",
+                                                          "none": "no collective"}[args.collect])
+            if world > 1 else "single GPU",
+            "collect": args.collect,
             "weights": "deterministic filler sha256:" + sha[:16],
         },
     }

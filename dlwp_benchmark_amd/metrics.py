@@ -28,6 +28,15 @@ class RolloutMetrics:
         self.std = std.float() if std is not None else None
         self.clim = climatology.float() if climatology is not None else None
         self.group = group
+        self._dev = {}   # device -> (latw, std, clim) copies made once
+
+    def _on(self, dev):
+        key = str(dev)
+        if key not in self._dev:
+            self._dev[key] = (self.latw.to(dev).contiguous(),
+                              self.std.to(dev).contiguous() if self.std is not None else None,
+                              self.clim.to(dev).contiguous() if self.clim is not None else None)
+        return self._dev[key]
 
     def sums(self, out: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """double [4, K, C] sums of this rank's samples (see dlwp_weighted_error_sums_f32)."""
@@ -38,9 +47,7 @@ class RolloutMetrics:
         if target.shape != out.shape:
             raise _lib.DlwpError(f"target shape {tuple(target.shape)} != output shape {tuple(out.shape)}")
         dev = out.device
-        latw = self.latw.to(dev)
-        std = self.std.to(dev).contiguous() if self.std is not None else None
-        clim = self.clim.to(dev).contiguous() if self.clim is not None else None
+        latw, std, clim = self._on(dev)
         sums = torch.empty(4, k, c, dtype=torch.float64, device=dev)
         lib = _lib.load()
         with torch.cuda.device(dev):
@@ -53,18 +60,20 @@ class RolloutMetrics:
     def __call__(self, out: torch.Tensor, target: torch.Tensor, world_size: int = 1):
         """Returns {"rmse": [K, C], "acc": [K, C] or None} over ALL ranks' samples."""
         s = self.sums(out, target)
-        n = torch.tensor([float(out.shape[0])], dtype=torch.float64, device=out.device)
+        n_samples = float(out.shape[0])
         if world_size > 1:
             import torch.distributed as dist
 
             host = dist.get_backend(self.group) != "nccl"
-            buf = torch.cat([s.flatten(), n])
+            buf = torch.empty(s.numel() + 1, dtype=torch.float64, device=out.device)
+            buf[:-1].copy_(s.flatten())
+            buf[-1:].fill_(n_samples)   # shards may differ by one sample: the count travels with the sums
             if host:
                 buf = buf.cpu()
             dist.all_reduce(buf, group=self.group)
             buf = buf.to(out.device)
-            s, n = buf[:-1].view_as(s), buf[-1:]
-        count = n * out.shape[-2] * out.shape[-1]
+            s, n_samples = buf[:-1].view_as(s), buf[-1:]
+        count = n_samples * out.shape[-2] * out.shape[-1]
         rmse = torch.sqrt(s[0] / count)
         acc = s[1] / torch.sqrt(s[2] * s[3]) if self.clim is not None else None
         return {"rmse": rmse, "acc": acc}
