@@ -174,3 +174,47 @@ def test_bf16x6_matches_fp32_mfma_kernels():
     assert max(per_step_rel_l2(a, b)) < 2e-6
     assert max(per_step_rel_l2(a, want)) <= TOL
     assert max(per_step_rel_l2(b, want)) <= TOL
+
+
+@pytest.mark.parametrize("h,w,batch,rows", [(128, 64, 3, None), (32, 64, 5, None), (64, 64, 3, "4"), (64, 128, 2, None)])
+def test_fno_trunk_variants_match_oracle(h, w, batch, rows, monkeypatch):
+    """The fused trunk at its other group sizes (H = 128 -> 16 workgroups per sample, H = 32 -> 4), with four rows per
+    workgroup, and the unfused kernels a 128-wide grid falls back to -- each against the oracle."""
+    import subprocess, sys, os, json
+
+    # DLWP_TRUNK_ROWS is read once per process: run the forced-rows case in a child process
+    if rows is not None:
+        code = ("import sys; sys.path.insert(0, 'tests'); import torch, test_fno_gpu as T;"
+                f"T._trunk_case({h}, {w}, {batch})")
+        env = dict(os.environ, DLWP_TRUNK_ROWS=rows)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    _trunk_case(h, w, batch)
+
+
+def _trunk_case(h, w, batch):
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    ref, hip = _make_pair(**NS_KW)
+    _, _, prog = navier_stokes(batch, 4, h, w, seed=5)
+    with torch.no_grad():
+        want = ref(prognostic=prog)
+    got = hip(prognostic=prog.to(_dev()))
+    torch.cuda.synchronize()
+    errs = per_step_rel_l2(got, want)
+    assert max(errs) <= TOL, f"{h}x{w}: per-step rel L2 {['%.2e' % e for e in errs]}"
+
+
+def test_fno_large_batches_cut_into_resident_chunks():
+    """More samples than fit the GPU at one workgroup per CU: the trunk is launched per resident chunk (32 + 8, 3 x 32 + 4)."""
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    _, hip = _make_pair(**NS_KW)
+    prog = navier_stokes(100, 3, 64, 64, seed=9)[2].to(_dev())
+    full = hip(prognostic=prog)
+    assert bool(torch.isfinite(full).all())
+    for lo, hi in ((0, 40), (37, 41), (96, 100)):
+        part = hip(prognostic=prog[lo:hi].contiguous())
+        assert max(per_step_rel_l2(part, full[lo:hi])) <= 1e-6
