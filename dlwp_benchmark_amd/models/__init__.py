@@ -11,7 +11,7 @@ from .fourcastnet import AFNONet, FourCastNet
 from .pangu import PanguWeather
 from .spectral import SpectralConv2d
 from .swin import SwinTransformer, SwinTransformerHPX
-from .unet import ConvLSTM, HEALPixLayer, HEALPixPadding, UNet, UNetHPX
+from .unet import ConvLSTM, HEALPixLayer, HEALPixPadding, MUNetHPX, UNet, UNetHPX
 
 __all__ = ["FNO2DModule", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "SwinTransformerHPX", "UNet",
-           "UNetHPX", "ConvLSTM", "HEALPixPadding", "HEALPixLayer"]
+           "UNetHPX", "MUNetHPX", "ConvLSTM", "HEALPixPadding", "HEALPixLayer"]

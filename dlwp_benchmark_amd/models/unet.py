@@ -56,16 +56,75 @@ class HEALPixLayer(nn.Module):
 
     def __init__(self, layer=nn.Conv2d, **kwargs):
         super().__init__()
-        if layer is not nn.Conv2d or kwargs.get("kernel_size", 3) != 3 or kwargs.get("dilation", 1) != 1:
-            raise NotImplementedError("only HEALPixLayer(Conv2d, kernel_size=3, dilation=1) has a fused kernel")
         kwargs = dict(kwargs)
-        kwargs["padding"] = 0
         kwargs.pop("enable_nhwc", None), kwargs.pop("enable_healpixpad", None)
+        if layer is ResidualBlock or layer == "ResidualBlock":
+            # not a convolution class: the reference adds no padding layer of its own (healpix.py:86-97), the block
+            # pads in front of its two convolutions itself
+            self.layers = nn.Sequential(ResidualBlock(**kwargs))
+            return
+        if layer is not nn.Conv2d or kwargs.get("kernel_size", 3) != 3 or kwargs.get("dilation", 1) != 1:
+            raise NotImplementedError("only HEALPixLayer(Conv2d, kernel_size=3, dilation=1) and "
+                                      "HEALPixLayer(ResidualBlock) have fused kernels")
+        kwargs["padding"] = 0
         self.layers = nn.Sequential(HEALPixPadding(1), nn.Conv2d(**kwargs))
 
     def forward(self, x, act: int = 0, x1=None):
+        if isinstance(self.layers[0], ResidualBlock):
+            return self.layers[0](x)
         conv = self.layers[1]
         return ops.conv3x3_hpx(x, conv.weight, conv.bias, act, x1=x1)
+
+
+class ResidualBlock(nn.Module):
+    """reference models/unet/unet.py:839-901 on the HEALPix mesh: pre-activation wide residual block.  Each
+    `HEALPixPadding(1) -> Conv2d(3x3, padding 0)` is one dlwp_conv3x3_hpx_f32 launch, the activation in front of the
+    second convolution rides in the first one's epilogue when there is no GroupNorm between them."""
+
+    def __init__(self, in_channels: int, out_channels: int, activation=None, norm: bool = False, n_groups: int = 1,
+                 kernel_size=3, padding=1, mesh=None):
+        super().__init__()
+        if mesh != "healpix":
+            raise NotImplementedError("ModernUNet is only runnable on the HEALPix mesh in the reference (SURVEY.md 8c)")
+        if kernel_size != 3:
+            raise NotImplementedError("only 3x3 residual blocks have a fused kernel")
+        activation = _resolve_activation(activation) if activation is not None else nn.GELU()
+        if not isinstance(activation, nn.GELU):
+            raise NotImplementedError("ResidualBlock: only GELU (the reference default) is wired to the fused kernels")
+        self.activation = activation
+        self.mesh = mesh
+        self.cylinder_pad = HEALPixPadding(padding=1)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=0)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=0)
+        with torch.no_grad():   # zero_module (unet.py:762-766)
+            self.conv2.weight.zero_(), self.conv2.bias.zero_()
+        self.shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=(1, 1)) if in_channels != out_channels \
+            else nn.Identity()
+        self.norm1 = nn.GroupNorm(n_groups, in_channels) if norm else nn.Identity()
+        self.norm2 = nn.GroupNorm(n_groups, out_channels) if norm else nn.Identity()
+
+    def forward(self, x):
+        gelu = ops.act_code(self.activation)
+        h = F.gelu(self.norm1(x))
+        if isinstance(self.norm2, nn.Identity):
+            h = ops.conv3x3_hpx(h, self.conv1.weight, self.conv1.bias, gelu)
+        else:
+            h = F.gelu(self.norm2(ops.conv3x3_hpx(h, self.conv1.weight, self.conv1.bias, 0)))
+        h = ops.conv3x3_hpx(h, self.conv2.weight, self.conv2.bias, 0)
+        return h + self.shortcut(x)
+
+
+class MiddleBlock(nn.Module):
+    """unet.py:904-946 (attention is an Identity in the reference)."""
+
+    def __init__(self, in_channels: int, attention: bool = False, activation=None, norm: bool = False, mesh=None):
+        super().__init__()
+        self.res1 = ResidualBlock(in_channels, in_channels, activation=activation, norm=norm, mesh=mesh)
+        self.attn = nn.Identity()
+        self.res2 = ResidualBlock(in_channels, in_channels, activation=activation, norm=norm, mesh=mesh)
+
+    def forward(self, x):
+        return self.res2(self.res1(x))
 
 
 def _resolve_activation(activation):
@@ -248,6 +307,90 @@ class UNetHPX(UNet):
             rollout_into(self.one_step, ctx, out, fold5(constants) if constants is not None else None,
                          fold5(prescribed) if prescribed is not None else None, fold5(prognostic))
             return out.reshape(b, f, t_total - ctx, cg, h, w).permute(0, 2, 3, 1, 4, 5).contiguous()
+
+
+class _ModernUNetEncoder(nn.Module):
+    """unet.py:559-632, healpix branch."""
+
+    def __init__(self, in_channels, hidden_channels):
+        super().__init__()
+        self.attn = nn.Identity()
+        channels = [in_channels] + list(hidden_channels)
+        layers = []
+        for c_idx in range(len(channels) - 1):
+            c_in, c_out = channels[c_idx], channels[c_idx + 1]
+            first = nn.Conv2d(c_in, c_in, (3, 3), (2, 2), (1, 1)) if c_idx > 0 else nn.Conv2d(c_in, c_in, (1, 1), (1, 1), (0, 0))
+            layers.append(nn.Sequential(first, HEALPixLayer(layer=ResidualBlock, in_channels=c_in, out_channels=c_out,
+                                                             kernel_size=3, padding=0, mesh="healpix"), self.attn))
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer[1](layer[0](x))
+        return x
+
+
+class _ModernUNetDecoder(nn.Module):
+    """unet.py:634-760, healpix branch, as it RUNS: the skip concatenation of :747-751 tests for ResidualBlock
+    instances, the sub-modules are HEALPixLayer wrappers, so no skip is ever concatenated (the channel counts of
+    the constructor are consistent with exactly that)."""
+
+    def __init__(self, hidden_channels, out_channels, activation):
+        super().__init__()
+        final_out = 2 * hidden_channels[0]
+        hidden = list(hidden_channels)[::-1]
+        self.attn = nn.Identity()
+        self.activation = activation
+        layers = []
+        c_out2 = None
+        for c_idx in range(len(hidden)):
+            c_out = hidden[c_idx]
+            c_in_ = c_out if c_idx == 0 else 2 * hidden[c_idx]
+            c_out2 = 2 * hidden[c_idx + 1] if c_idx + 1 < len(hidden) else 2 * hidden[c_idx]
+            layer = [HEALPixLayer(layer=ResidualBlock, in_channels=c_in_, out_channels=c_out, kernel_size=3, padding=0,
+                                  mesh="healpix"), self.attn,
+                     HEALPixLayer(layer=ResidualBlock, in_channels=c_out, out_channels=c_out2, kernel_size=3, padding=0,
+                                  mesh="healpix")]
+            if c_idx < len(hidden) - 1:
+                layer.append(nn.ConvTranspose2d(c_out2, c_out2, (4, 4), (2, 2), (1, 1)))
+            layers.append(nn.Sequential(*layer))
+        self.layers = nn.ModuleList(layers)
+        self.output_layer = nn.Conv2d(c_out2, out_channels, kernel_size=1)
+        with torch.no_grad():   # zero_module
+            self.output_layer.weight.zero_(), self.output_layer.bias.zero_()
+        self.final_norm = nn.GroupNorm(8, final_out)
+
+    def forward(self, x):
+        for layer in self.layers:
+            for sub in layer:
+                x = sub(x)
+        return self.output_layer(self.activation(self.final_norm(x)))
+
+
+class MUNetHPX(UNetHPX):
+    """reference models/unet/unet.py:205-269 (`MUNetHPX`, the PDE-Refiner style ModernUNet :72-203 on the HEALPix
+    mesh).  Same constructor kwargs, module tree / state-dict keys and
+    forward(constants, prescribed, prognostic) with face-carrying tensors [B, T, C, 12, H, W].  `recurrent=True`
+    (a hard-coded cuda:0 ConvLSTM cell, :689-703) and attention (an Identity in the reference) are not built."""
+
+    def __init__(self, constant_channels: int = 4, prescribed_channels: int = 0, prognostic_channels: int = 1,
+                 hidden_channels: list = [64, 128, 256, 1024], activation=nn.GELU(), context_size: int = 1,
+                 mesh: str = "healpix", attention: bool = False, norm: bool = False, recurrent: bool = False, **kwargs):
+        HipBackbone.__init__(self)
+        if recurrent:
+            raise NotImplementedError("MUNetHPX(recurrent=True) is not built")
+        activation = _resolve_activation(activation)
+        if not isinstance(activation, nn.GELU):
+            raise NotImplementedError("MUNetHPX: only GELU is wired to the fused kernels")
+        self.context_size = int(context_size)
+        self.mesh = "healpix"
+        in_channels = constant_channels + (prescribed_channels + prognostic_channels) * context_size
+        self.encoder = _ModernUNetEncoder(in_channels, list(hidden_channels))
+        self.middle = MiddleBlock(in_channels=hidden_channels[-1], norm=norm, activation=activation, mesh="healpix")
+        self.decoder = _ModernUNetDecoder(list(hidden_channels), prognostic_channels, activation)
+
+    def one_step(self, x):
+        return self.decoder(self.middle(self.encoder(x)))
 
 
 class _ConvLSTMCell(nn.Module):

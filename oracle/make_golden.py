@@ -199,6 +199,15 @@ HPX_SWIN_CASES = {
 }
 
 
+HPX_MUNET_CASES = {
+    # hidden [16, 8] is the "inverted" shape of configs/model/modernunet_small_inverted.yaml at reduced width
+    "munethpx_h16_8_norm": (dict(constant_channels=2, prescribed_channels=1, prognostic_channels=3, hidden_channels=[16, 8],
+                                 context_size=1, norm=True), (2, 3), (8, 8)),
+    "munethpx_h8_16": (dict(constant_channels=0, prescribed_channels=0, prognostic_channels=2, hidden_channels=[8, 16],
+                            context_size=2, norm=False), (1, 4), (8, 8)),
+}
+
+
 def hpx_inputs(tag, cfg, batch, frames, hw):
     h, w = hw
     cc, cp, cg = cfg["constant_channels"], cfg["prescribed_channels"], cfg["prognostic_channels"]
@@ -223,6 +232,20 @@ def gen_hpx(ref):
         sha = W.fill_state_dict(m, gain=1.0)
         constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
         with torch.no_grad():
+            y = m(constants=constants, prescribed=prescribed, prognostic=prognostic)
+        spec = [(k, list(v.shape)) for k, v in m.named_parameters()]
+        full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]
+        _save(f"model_{tag}", y=y.numpy().astype(np.float32), sha=np.array(sha), param_spec=np.array(json.dumps(spec)),
+              state_spec=np.array(json.dumps(full)))
+    import contextlib
+    import io
+
+    for tag, (cfg, (batch, frames), hw) in HPX_MUNET_CASES.items():
+        m = ref["unet"].MUNetHPX(**cfg)
+        m.eval()
+        sha = W.fill_state_dict(m, gain=1.0)   # the reference zero-initialises conv2 / output_layer: fill everything
+        constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):   # the reference forward prints shapes
             y = m(constants=constants, prescribed=prescribed, prognostic=prognostic)
         spec = [(k, list(v.shape)) for k, v in m.named_parameters()]
         full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]

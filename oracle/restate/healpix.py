@@ -98,6 +98,10 @@ def unet_hpx_one_step(sd, cfg, x):
 def unet_hpx_rollout(sd, cfg, constants, prescribed, prognostic):
     """unet.py:331-383 with the HPX `_prepare_inputs` (:413-426): tensors carry a face axis
     [B, T, C, 12, H, W]; faces are folded into the batch for the backbone."""
+    return _hpx_rollout(lambda x: unet_hpx_one_step(sd, cfg, x), cfg, constants, prescribed, prognostic)
+
+
+def _hpx_rollout(one_step, cfg, constants, prescribed, prognostic):
     ctx = cfg["context_size"]
     b = prognostic.shape[0]
     fold_c = lambda t: t.permute(0, 2, 1, 3, 4).reshape(-1, t.shape[1], t.shape[3], t.shape[4])          # b c f h w
@@ -117,7 +121,58 @@ def unet_hpx_rollout(sd, cfg, constants, prescribed, prognostic):
         if presc_t is not None:
             parts.append(fold_t(presc_t))
         parts.append(fold_t(prog_t))
-        y = unet_hpx_one_step(sd, cfg, torch.cat(parts, dim=1))
+        y = one_step(torch.cat(parts, dim=1))
         y = y.reshape(b, 12, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)                   # b tc f h w
         outs.append(prog_t[:, -1] + y)
     return torch.stack(outs, dim=1)
+
+
+# ------------------------------------------------------------------------------------------
+# ModernUNet on the HEALPix mesh (MUNetHPX), SURVEY.md 8a row a16
+# ------------------------------------------------------------------------------------------
+def residual_block(sd, prefix, x, norm_groups=None):
+    """unet.py:839-901 `ResidualBlock` with mesh == "healpix": pre-activation, HEALPixPadding(1) in front of both
+    3x3 convolutions (padding 0), 1x1 shortcut when the channel count changes; GroupNorm only if the block was
+    built with norm=True (the MiddleBlock of a norm=True model, n_groups = 1)."""
+    def norm(t, name):
+        if norm_groups is None:
+            return t
+        return F.group_norm(t, norm_groups, sd[f"{prefix}.{name}.weight"], sd[f"{prefix}.{name}.bias"])
+
+    h = F.gelu(norm(x, "norm1"))
+    h = F.conv2d(healpix_pad(h, 1), sd[prefix + ".conv1.weight"], sd[prefix + ".conv1.bias"])
+    h = F.gelu(norm(h, "norm2"))
+    h = F.conv2d(healpix_pad(h, 1), sd[prefix + ".conv2.weight"], sd[prefix + ".conv2.bias"])
+    if prefix + ".shortcut.weight" in sd:
+        x = F.conv2d(x, sd[prefix + ".shortcut.weight"], sd[prefix + ".shortcut.bias"])
+    return h + x
+
+
+def munet_hpx_one_step(sd, cfg, x):
+    """ModernUNetEncoder (unet.py:559-632) -> MiddleBlock (:904-946) -> ModernUNetDecoder (:634-760) as they RUN
+    on the HEALPix mesh.  Kept on purpose: the decoder never concatenates skips (its isinstance test looks for
+    ResidualBlock but the sub-modules are HEALPixLayer wrappers, :747-751), the first decoder block of every level
+    but the first therefore receives the 2*hidden channels of the level below; down-sampling is a plain zero-padded
+    3x3 stride-2 convolution per face, up-sampling a ConvTranspose2d(4, 2, 1) per face."""
+    hidden = list(cfg["hidden_channels"])
+    norm = cfg.get("norm", False)
+    nl = len(hidden)
+    for li in range(nl):
+        w, b = sd[f"encoder.layers.{li}.0.weight"], sd[f"encoder.layers.{li}.0.bias"]
+        x = F.conv2d(x, w, b, stride=2, padding=1) if li > 0 else F.conv2d(x, w, b)
+        x = residual_block(sd, f"encoder.layers.{li}.1.layers.0", x)
+    x = residual_block(sd, "middle.res1", x, 1 if norm else None)
+    x = residual_block(sd, "middle.res2", x, 1 if norm else None)
+    for li in range(nl):
+        x = residual_block(sd, f"decoder.layers.{li}.0.layers.0", x)
+        x = residual_block(sd, f"decoder.layers.{li}.2.layers.0", x)
+        if li < nl - 1:
+            x = F.conv_transpose2d(x, sd[f"decoder.layers.{li}.3.weight"], sd[f"decoder.layers.{li}.3.bias"], stride=2,
+                                   padding=1)
+    x = F.gelu(F.group_norm(x, 8, sd["decoder.final_norm.weight"], sd["decoder.final_norm.bias"]))
+    return F.conv2d(x, sd["decoder.output_layer.weight"], sd["decoder.output_layer.bias"])
+
+
+def munet_hpx_rollout(sd, cfg, constants, prescribed, prognostic):
+    """ModernUNet.forward (unet.py:139-203) with MUNetHPX._prepare_inputs (:234-269)."""
+    return _hpx_rollout(lambda x: munet_hpx_one_step(sd, cfg, x), cfg, constants, prescribed, prognostic)

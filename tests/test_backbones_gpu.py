@@ -215,3 +215,24 @@ def test_swin_hpx_rollout_matches_reference_golden():
         assert got.shape == want.shape
         errs = per_step_rel_l2(got, want)
         assert max(errs) <= TOL, f"{tag}: per-step rel L2 {['%.2e' % e for e in errs]}"
+
+
+def test_munet_hpx_rollout_matches_reference_golden():
+    """a16: ModernUNet residual / middle blocks with GroupNorm on the HEALPix mesh vs the real MUNetHPX."""
+    import dlwp_benchmark_amd.models as M
+    from dlwp_benchmark_amd.weights import fill_by_spec
+    from oracle.make_golden import HPX_MUNET_CASES, hpx_inputs
+
+    for tag, (cfg, (batch, frames), hw) in HPX_MUNET_CASES.items():
+        g = load_golden(f"model_{tag}")
+        sd, sha = fill_by_spec(json.loads(str(g["param_spec"])), gain=1.0)
+        assert sha == str(g["sha"])
+        model = M.MUNetHPX(**cfg)
+        model.load_state_dict(sd, strict=True)
+        model = model.to("cuda:0").eval()
+        dev = lambda t: t.to("cuda:0") if t is not None else None
+        got = model(*[dev(t) for t in hpx_inputs(tag, cfg, batch, frames, hw)])
+        want = torch.from_numpy(g["y"])
+        assert got.shape == want.shape
+        errs = per_step_rel_l2(got, want)
+        assert max(errs) <= TOL, f"{tag}: per-step rel L2 {['%.2e' % e for e in errs]}"

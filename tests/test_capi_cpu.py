@@ -82,8 +82,13 @@ def test_state_dicts_match_reference_layout():
         want = {k: (tuple(s), d) for k, s, d in json.loads(str(g["state_spec"]))}
         got = {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in M.UNetHPX(**cfg).state_dict().items()}
         assert got == want, (tag, sorted(set(want) ^ set(got))[:6])
-    from oracle.make_golden import HPX_SWIN_CASES
+    from oracle.make_golden import HPX_MUNET_CASES, HPX_SWIN_CASES
 
+    for tag, (cfg, _, _) in HPX_MUNET_CASES.items():
+        g = load_golden(f"model_{tag}")
+        want = {k: (tuple(s), d) for k, s, d in json.loads(str(g["state_spec"]))}
+        got = {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in M.MUNetHPX(**cfg).state_dict().items()}
+        assert got == want, (tag, sorted(set(want) ^ set(got))[:6])
     for tag, (cfg, _, _) in HPX_SWIN_CASES.items():
         g = load_golden(f"model_{tag}")
         want = {k: (tuple(s), d) for k, s, d in json.loads(str(g["state_spec"]))}

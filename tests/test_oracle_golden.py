@@ -75,7 +75,7 @@ def test_backbone_restatement_matches_reference(tag):
 # HEALPix (8f f3): face padding + HEALPix U-Net restatements vs the real reference
 # ------------------------------------------------------------------------------------------
 from dlwp_benchmark_amd import weights as W
-from oracle.make_golden import HPX_MODEL_CASES, HPX_PAD_CASES, HPX_SWIN_CASES, hpx_inputs
+from oracle.make_golden import HPX_MODEL_CASES, HPX_MUNET_CASES, HPX_PAD_CASES, HPX_SWIN_CASES, hpx_inputs
 from oracle.restate import healpix as R_hpx
 
 
@@ -111,6 +111,22 @@ def test_swin_hpx_restatement_matches_reference(tag):
     constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
     with torch.no_grad():
         y = R_swin.swin_hpx_rollout(sd, cfg, constants, prescribed, prognostic)
+    ref = torch.from_numpy(g["y"])
+    assert y.shape == ref.shape
+    assert max(rel_l2(y[:, t], ref[:, t]) for t in range(ref.shape[1])) < 1e-6
+
+
+@pytest.mark.parametrize("tag", list(HPX_MUNET_CASES))
+def test_munet_hpx_restatement_matches_reference(tag):
+    """ResidualBlock / MiddleBlock / GroupNorm, pinned through the only ModernUNet the
+    reference can run (MUNetHPX)."""
+    cfg, (batch, frames), hw = HPX_MUNET_CASES[tag]
+    g = load_golden(f"model_{tag}")
+    sd, sha = fill_by_spec(json.loads(str(g["param_spec"])), gain=1.0)
+    assert sha == str(g["sha"]), "filler drifted: regenerate fixtures"
+    constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
+    with torch.no_grad():
+        y = R_hpx.munet_hpx_rollout(sd, cfg, constants, prescribed, prognostic)
     ref = torch.from_numpy(g["y"])
     assert y.shape == ref.shape
     assert max(rel_l2(y[:, t], ref[:, t]) for t in range(ref.shape[1])) < 1e-6
