@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
           pv0[it] = src[2 * C + e];
         }
       } else {
-        const int key = i / EP, e = 2 * (i % EP);
+        // lanes 2m / 2m+1 hold the same element pair of keys 2kp / 2kp+1, so that the V^T tile can be written
+        // as whole dwords (two keys each) after one lane exchange -- see stage_write
+        const int key = 2 * (i / (2 * EP)) + (i & 1), e = 2 * ((i >> 1) % EP);
         const int kn = kt * KT + key;
         pk0[it] = 0.f; pk1[it] = 0.f; pv0[it] = 0.f; pv1[it] = 0.f; pinfo[it] = -1;
         if (i < KT * EP && kn < N) {
@@ -236,14 +238,19 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
           s_v[key * LDV + e] = pv0[it];
         }
       } else {
+        // V^T[dim][key]: the first version wrote it with two 16-bit stores per thread (element pair e, e+1 of one
+        // key): 4-way bank conflicts on sub-dword writes, 13 % of the CU's cycles (profiles/
+        // r01_f_swin_attention_sq_counters.txt).  Now the lane pair (2m, 2m+1) = keys (2kp, 2kp+1) swaps halves and
+        // each lane writes ONE dword: row e for the even lane, row e+1 for the odd one.
+        const unsigned vp = cvt_pk_bf16(pv0[it], pv1[it]);
+        const unsigned vq = (unsigned)__shfl_xor((int)vp, 1);
         if (i < KT * EP) {
-          const int key = i / EP, e = 2 * (i % EP);
+          const int kbit = i & 1, kp = i / (2 * EP), key = 2 * kp + kbit, e = 2 * ((i >> 1) % EP);
           if (e == 0) s_info[key] = pinfo[it];
           *reinterpret_cast<unsigned*>(s_kb + key * LDKB + e) = cvt_pk_bf16(pk0[it], pk1[it]);
           if (e < 16 * DB) {
-            const unsigned vp = cvt_pk_bf16(pv0[it], pv1[it]);
-            s_vb[e * LDVB + key] = (unsigned short)(vp & 0xFFFFu);
-            s_vb[(e + 1) * LDVB + key] = (unsigned short)(vp >> 16);
+            const unsigned word = kbit ? ((vq >> 16) | (vp & 0xFFFF0000u)) : ((vp & 0xFFFFu) | (vq << 16));
+            *reinterpret_cast<unsigned*>(s_vb + (e + kbit) * LDVB + 2 * kp) = word;
           }
         }
       }
