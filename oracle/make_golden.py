@@ -106,6 +106,19 @@ MODEL_CASES = {
     "convlstm_h8_32x64": ("convlstm", dict(batch_size=2, constant_channels=4, prescribed_channels=1,
                                            prognostic_channels=3, hidden_sizes=[8, 8], height=32, width=64, bias=True,
                                            context_size=2), (2, 6), 1.0),
+    # the BASELINE configurations at FULL width (C3, C4, C5): one initial condition, two steps; only the output
+    # trajectory and the SHA of the filler weights are committed
+    "swin_c3_full": ("swin", dict(context_size=1, img_height=32, img_width=64, patch_size=1, constant_channels=4,
+                                  prescribed_channels=1, prognostic_channels=3, embed_dim=96, depths=[4, 4],
+                                  num_heads=[4, 4], mlp_ratio=4, qkv_bias=True, drop_path_rate=0.2,
+                                  norm_layer="nn.LayerNorm", patch_norm=True), (1, 3), 0.7),
+    "afno_c4_full": ("afno", dict(img_height=128, img_width=256, patch_size=[1, 1], constant_channels=4,
+                                  prescribed_channels=1, prognostic_channels=3, filter="AFNO2D", embed_dim=64, depth=4,
+                                  mlp_ratio=4.0, num_blocks=4, sparsity_threshold=0.01, hard_thresholding_fraction=1.0,
+                                  context_size=1, use_pos_embed=True), (1, 3), 0.7),
+    "pangu_c5_full": ("pangu", dict(constant_channels=4, prescribed_channels=1, prognostic_channels=13, embed_dim=192,
+                                    num_heads=[6, 12, 12, 6], window_size=[2, 6, 12], patch_size=[1, 1], n_lat=128,
+                                    n_lon=256, context_size=1), (1, 3), 0.7),
 }
 
 
