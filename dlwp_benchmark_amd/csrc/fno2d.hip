@@ -1073,6 +1073,9 @@ struct TrunkParams {
   const float2* wt[kTrunkMaxLayers];   // [M2][M1][32][32]
   float* xpart;        // [S][G][M2][M1][2][32]
   float* obuf;         // [S][M2][M1][2][32]
+  long long xpart_par, obuf_par;   // LL protocol: distance (floats) to the second (odd-layer) copy of each buffer
+  unsigned layer0;     // LL protocol: spectral layers already run on these buffers since they were armed
+  unsigned* xcc_tab;   // LL protocol: [S][32] (tag << 4 | XCC id) of every workgroup of a sample's group
   unsigned* ctr;       // one counter per sample, 32 dwords apart
   unsigned epoch;      // barriers already counted on these counters
   float fwd_scale;
@@ -1145,6 +1148,29 @@ __device__ __forceinline__ void ld4_sc1_x4(const float* base, unsigned o0, unsig
       : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base)
       : "memory");
 }
+// Flag-in-data hand-off ("LL" protocol): the exchange buffers are armed with a sentinel bit pattern (a quiet NaN with a
+// payload no arithmetic produces); a consumer re-loads until none of the dwords it needs is the sentinel, so the data
+// itself is the flag: no store drain, no counter round trip, no workgroup barrier on the producer side.
+constexpr unsigned kSentinel = 0x7fc0deadu;
+__device__ __forceinline__ bool has_sentinel(const f32x4& v) {
+  return (__float_as_uint(v[0]) == kSentinel) | (__float_as_uint(v[1]) == kSentinel) |
+         (__float_as_uint(v[2]) == kSentinel) | (__float_as_uint(v[3]) == kSentinel);
+}
+__device__ __forceinline__ void st4_sc1(const float* base, unsigned off, const f32x4& v) {
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void st4_l2(const float* base, unsigned off, const f32x4& v) {   // stays in this XCD's L2
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+// Exchange stores of the flag-in-data protocol.  `fast` = every workgroup of the sample's group was FOUND to sit on the
+// same XCD (HW_REG_XCC_ID exchanged during the first layer): a plain store keeps the line in that XCD's L2, where the
+// group's L1-bypassing (sc1) loads hit it after ~0.2 us instead of going to the Infinity Cache (~0.9 us round trip).
+// Otherwise the write-through sc1 form that is correct across XCDs.
+__device__ __forceinline__ void st_xchg(float* p, float v, bool fast) {
+  if (fast) *p = v;   // (not volatile: hipcc turns volatile stores into sc0 sc1 + a wait each, 6x slower)
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the
 // weight prefetches that are meant to stay in flight across the barrier.
 __device__ __forceinline__ void lds_barrier() {
@@ -1155,7 +1181,7 @@ __device__ __forceinline__ f32x4 shfl_xor4(f32x4 v, int m) {
 }
 
 // ROWS = grid rows (= waves) per workgroup, G = workgroups per sample = H / ROWS (see trunk_rows() for the choice).
-template <int ROWS, int G>
+template <int ROWS, int G, bool LL>
 __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkParams p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int W = 64, KP = 16, C = kC, NT = 64 * ROWS;
@@ -1168,6 +1194,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   float* s_t = s_x + ROWS * 128;                             // [16][64]      T  (inverse W-DFT twiddles)
   float* s_tt = s_t + KP * W;                             // [64][16]      TT (forward W-DFT twiddles)
   int* s_fail = reinterpret_cast<int*>(s_tt + W * KP);
+  int* s_fast = s_fail + 1;                               // LL: the sample's group shares one XCD (found in layer 0)
   const int H = p.H, M1 = p.M1, M2 = p.M2, NM = M1 * M2;
   int sample, member;
   {
@@ -1186,7 +1213,15 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   const int gs = p.sample0 + sample;                      // sample index in the activation tensors
   const long long pix = (long long)h * W + 4 * j;
   unsigned* ctr = p.ctr + sample * 32;
-  if (tid == 0) *s_fail = 0;
+  if (tid == 0) {
+    *s_fail = 0;
+    *s_fast = 0;
+    if (LL) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xFu;   // HW_REG_XCC_ID
+      __hip_atomic_store(p.xcc_tab + sample * 32 + member, ((p.layer0 + 1u) << 4) | xcc, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   for (int i = tid; i < ROWS * KP * C; i += NT) s_z[i] = 0.f;   // k' slots beyond 2*M2 stay zero
   for (int i = tid; i < KP * W; i += NT) {
     s_t[i] = p.t[i];
@@ -1229,10 +1264,13 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   const int ks3 = (2 * M1 + 3) / 4;
   const int per = (NM + G - 1) / G;                       // modes per workgroup in P2
   const int m_lo = member * per, m_hi = (m_lo + per < NM) ? m_lo + per : NM;
-  float* xp_mine = p.xpart + ((long long)sample * G + member) * NM * 64;
-  const float* xp_grp = p.xpart + (long long)sample * G * NM * 64;
-  float* ob = p.obuf + (long long)sample * NM * 64;
+  // LL: the exchange buffers exist twice (layer parity), p.xpart / p.obuf point at parity 0 and the second copy
+  // lies p.xpart_par / p.obuf_par floats further
+  float* xp_mine0 = p.xpart + ((long long)sample * G + member) * NM * 64;
+  const float* xp_grp0 = p.xpart + (long long)sample * G * NM * 64;
+  float* ob0 = p.obuf + (long long)sample * NM * 64;
   unsigned target = p.epoch * (unsigned)G;
+
   int n_stamp = 0;
 #define DLWP_STAMP()                                                                                   \
   do {                                                                                                 \
@@ -1241,6 +1279,13 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   DLWP_STAMP();
 
   for (int l = 0; l < p.L; ++l) {
+    const int par = LL ? (int)((p.layer0 + (unsigned)l) & 1u) : 0;
+    float* xp_mine = xp_mine0 + par * p.xpart_par;
+    const float* xp_grp = xp_grp0 + par * p.xpart_par;
+    float* ob = ob0 + par * p.obuf_par;
+    float* ob_other = ob0 + (par ^ 1) * p.obuf_par;
+    if (LL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's re-arming stores of the previous layer are done
+    const bool fast = LL && l > 0 && (*s_fast != 0);
     // operands that do not depend on data are requested before the barriers: the skip weights / bias of the row
     // phase and the weights of this wave's first two modes
     u32x4 wb[2][3];
@@ -1252,12 +1297,11 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) bias4[ot] = *reinterpret_cast<const f32x4*>(p.bias[l] + 16 * ot + 4 * g);
     float2 wreg[2][16];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int m = m_lo + wave + ROWS * u;
+    {
+      const int m = m_lo + wave;
       const float2* w = p.wt[l] + ((long long)(m < m_hi ? m : 0) * C + (lane >> 5) * 16) * C + (lane & 31);
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) wreg[u][cc] = w[cc * C];
+      for (int cc = 0; cc < 16; ++cc) wreg[0][cc] = w[cc * C];
     }
     lds_barrier();   // s_y complete (all rows of the workgroup)
     DLWP_STAMP();
@@ -1277,15 +1321,20 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
           const int r = 4 * g + r4;
           if (r < M1) {
             float* dst = xp_mine + (long long)(ky * M1 + r) * 64 + 16 * nt + j;
-            st_sc1(dst, dre[r4]);
-            st_sc1(dst + 32, dim[r4]);
+            if (LL) {
+              st_xchg(dst, dre[r4], fast);
+              st_xchg(dst + 32, dim[r4], fast);
+            } else {
+              st_sc1(dst, dre[r4]);
+              st_sc1(dst + 32, dim[r4]);
+            }
           }
         }
       }
     }
     DLWP_STAMP();
     target += (unsigned)G;
-    trunk_group_arrive(ctr);
+    if (!LL) trunk_group_arrive(ctr);
     // in the shadow of the barrier: the part of the row that does not need the spectrum, bias + 1x1 skip
     // convolution of the resident activation on the bf16 pipe (bf16x6)
     f32x4 acc[2][4];
@@ -1307,8 +1356,14 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma_bf16x6(wb[ot], bx, acc[ot][q]);
     }
-    trunk_group_wait(ctr, target, s_fail);
+    if (!LL) trunk_group_wait(ctr, target, s_fail);
     DLWP_STAMP();
+    {   // weights of the wave's second mode: requested now, they arrive while the partials are awaited
+      const int m = m_lo + wave + ROWS;
+      const float2* w = p.wt[l] + ((long long)(m < m_hi ? m : 0) * C + (lane >> 5) * 16) * C + (lane & 31);
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) wreg[1][cc] = w[cc * C];
+    }
     // ---- P2: channel mixing of this workgroup's share of the modes, two modes per pass.
     // lane (q4 = lane >> 4, quad = lane & 15) fetches floats 4 quad..4 quad+3 of the partials q4, q4+4, ...
     for (int up = 0; up < 2; ++up) {
@@ -1324,10 +1379,43 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         const bool va = qa < G, vb = (i0 + 1 < NI) && qb < G;
         const unsigned oa0 = (unsigned)((((va ? qa : 0) * NM + ma) * 64 + 4 * quad) * 4);
         const unsigned oa1 = (unsigned)((((vb ? qb : 0) * NM + ma) * 64 + 4 * quad) * 4);
-        const unsigned ob0 = (unsigned)((((va ? qa : 0) * NM + (has_b ? mb : ma)) * 64 + 4 * quad) * 4);
-        const unsigned ob1 = (unsigned)((((vb ? qb : 0) * NM + (has_b ? mb : ma)) * 64 + 4 * quad) * 4);
+        const unsigned obo0 = (unsigned)((((va ? qa : 0) * NM + (has_b ? mb : ma)) * 64 + 4 * quad) * 4);
+        const unsigned obo1 = (unsigned)((((vb ? qb : 0) * NM + (has_b ? mb : ma)) * 64 + 4 * quad) * 4);
         f32x4 v0, v1, v2, v3;
-        ld4_sc1_x4(xp_grp, oa0, oa1, ob0, ob1, v0, v1, v2, v3);
+        ld4_sc1_x4(xp_grp, oa0, oa1, obo0, obo1, v0, v1, v2, v3);
+        if (LL) {
+          int tries = 0;
+          while (__any((va && (has_sentinel(v0) || has_sentinel(v2))) || (vb && (has_sentinel(v1) || has_sentinel(v3))))) {
+            if (++tries > (1 << 16)) {
+              *s_fail = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            ld4_sc1_x4(xp_grp, oa0, oa1, obo0, obo1, v0, v1, v2, v3);
+          }
+          // re-arm what was consumed (this wave is the only reader of these modes' partials)
+          const f32x4 sent4 = {__uint_as_float(kSentinel), __uint_as_float(kSentinel), __uint_as_float(kSentinel),
+                               __uint_as_float(kSentinel)};
+          if (fast) {
+            if (va) {
+              st4_l2(xp_grp, oa0, sent4);
+              if (has_b) st4_l2(xp_grp, obo0, sent4);
+            }
+            if (vb) {
+              st4_l2(xp_grp, oa1, sent4);
+              if (has_b) st4_l2(xp_grp, obo1, sent4);
+            }
+          } else {
+            if (va) {
+              st4_sc1(xp_grp, oa0, sent4);
+              if (has_b) st4_sc1(xp_grp, obo0, sent4);
+            }
+            if (vb) {
+              st4_sc1(xp_grp, oa1, sent4);
+              if (has_b) st4_sc1(xp_grp, obo1, sent4);
+            }
+          }
+        }
         if (va) { sa += v0; sb += v2; }
         if (vb) { sa += v1; sb += v3; }
       }
@@ -1357,13 +1445,18 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         }
         acc.x += __shfl_xor(acc.x, 32);
         acc.y += __shfl_xor(acc.y, 32);
-        st_sc1(ob + (long long)m * 64 + lane, lane < 32 ? acc.x : acc.y);
+        if (LL) {
+          st_xchg(ob_other + (long long)m * 64 + lane, __uint_as_float(kSentinel), fast);   // every reader of the older O is done
+          st_xchg(ob + (long long)m * 64 + lane, lane < 32 ? acc.x : acc.y, fast);
+        } else {
+          st_sc1(ob + (long long)m * 64 + lane, lane < 32 ? acc.x : acc.y);
+        }
       }
       wave_lds_fence();
     }
     DLWP_STAMP();
     target += (unsigned)G;
-    trunk_group_barrier(ctr, target, s_fail);
+    if (!LL) trunk_group_barrier(ctr, target, s_fail);
     DLWP_STAMP();
     // ---- P3: inverse H-direction DFT for the own rows, columns (ky = wave, wave + ROWS, ..; o) -> s_z
     for (int ky = wave; ky < M2; ky += ROWS) {
@@ -1379,6 +1472,33 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         }
         f32x4 v0, v1, v2, v3;
         ld4_sc1_x4(ob, o[0], o[1], o[2], o[3], v0, v1, v2, v3);
+        if (LL) {
+          const bool k0 = 4 * lane < nflt, k1 = 4 * lane + 256 < nflt, k2 = 4 * lane + 512 < nflt, k3 = 4 * lane + 768 < nflt;
+          int tries = 0;
+          while (__any((k0 && has_sentinel(v0)) || (k1 && has_sentinel(v1)) || (k2 && has_sentinel(v2)) ||
+                       (k3 && has_sentinel(v3)))) {
+            if (++tries > (1 << 16)) {
+              *s_fail = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            ld4_sc1_x4(ob, o[0], o[1], o[2], o[3], v0, v1, v2, v3);
+          }
+        }
+        if (LL && l == 0 && wave == 0 && ky == 0) {
+          // O of layer 0 has arrived, so every workgroup of the group has run and published its XCC id: does the
+          // whole group share this XCD?  (decides the store flavour of all later exchanges, see st_xchg)
+          const unsigned want = (p.layer0 + 1u) << 4;
+          unsigned id = __hip_atomic_load(p.xcc_tab + sample * 32 + (lane < G ? lane : 0), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+          int tries = 0;
+          while (__any((id & ~0xFu) != want) && ++tries < 64)
+            id = __hip_atomic_load(p.xcc_tab + sample * 32 + (lane < G ? lane : 0), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned id0 = (unsigned)__builtin_amdgcn_readfirstlane((int)id);
+          const bool same = !__any(id != id0);
+          if (lane == 0) *s_fast = same ? 1 : 0;
+        }
         *reinterpret_cast<f32x4*>(s_tr + 4 * lane) = v0;
         *reinterpret_cast<f32x4*>(s_tr + 4 * lane + 256) = v1;
         *reinterpret_cast<f32x4*>(s_tr + 4 * lane + 512) = v2;
@@ -1862,7 +1982,8 @@ struct KernelTimer {
 };
 struct FnoWorkspace {
   float *h0, *h1, *ybuf, *zbuf;
-  float *xpart, *obuf;   // fused trunk: per-workgroup spectrum partials, mixed spectrum
+  float *xpart, *obuf;   // fused trunk: per-workgroup spectrum partials, mixed spectrum (two copies each)
+  size_t xpart_half, obuf_half;   // floats per copy
   unsigned* ctr;         // fused trunk: one group counter per sample (128 B apart)
   size_t total;
 };
@@ -1878,11 +1999,14 @@ FnoWorkspace carve(const dlwp_fno2d_plan* p, int B, void* base) {
   w.zbuf = reinterpret_cast<float*>(c + 2 * act + yz);
   const int G = (p->H + 3) / 4;   // most workgroups per sample the fused trunk uses
   const size_t nm = (size_t)p->sc.M1 * p->sc.M2 * 64 * 4;
-  const size_t xp = align_up((size_t)B * G * nm, 256), ob = align_up((size_t)B * nm, 256);
-  const size_t ct = align_up((size_t)B * kCtrStrideBytes, 256);
+  // two copies each (layer parity of the flag-in-data protocol)
+  const size_t xp = 2 * align_up((size_t)B * G * nm, 256), ob = 2 * align_up((size_t)B * nm, 256);
+  const size_t ct = 2 * align_up((size_t)B * kCtrStrideBytes, 256);   // group counters + XCC-id table
   w.xpart = reinterpret_cast<float*>(c + 2 * act + 2 * yz);
   w.obuf = reinterpret_cast<float*>(c + 2 * act + 2 * yz + xp);
   w.ctr = reinterpret_cast<unsigned*>(c + 2 * act + 2 * yz + xp + ob);
+  w.xpart_half = xp / 8;
+  w.obuf_half = ob / 8;
   w.total = 2 * act + 2 * yz + xp + ob + ct;
   return w;
 }
@@ -1957,20 +2081,42 @@ bool trunk_eligible(const dlwp_fno2d_plan* p) {
 }
 struct TrunkState {
   bool on = false;
-  unsigned epoch = 0;   // group barriers already counted since the counters were zeroed
+  unsigned epoch = 0;    // group barriers already counted since the counters were zeroed
+  unsigned layers = 0;   // spectral layers run since the exchange buffers were armed (flag-in-data protocol)
 };
+// Hand-off protocol of the fused trunk: 1 = flag-in-data (default), 0 = counter barriers (DLWP_TRUNK_LL=0).
+bool trunk_ll() {
+  static const bool on = [] {
+    const char* e = getenv("DLWP_TRUNK_LL");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
 int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, TrunkState& st, hipStream_t s) {
   st.on = trunk_eligible(p);
   st.epoch = 0;
-  if (st.on) DLWP_HIP_CHECK(hipMemsetAsync(ws.ctr, 0, (size_t)B * kCtrStrideBytes, s));
+  st.layers = 0;
+  if (st.on) {
+    DLWP_HIP_CHECK(hipMemsetAsync(ws.ctr, 0, 2 * align_up((size_t)B * kCtrStrideBytes, 256), s));
+    if (trunk_ll()) {   // arm both copies of both exchange buffers with the sentinel
+      DLWP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.xpart), (int)kSentinel, 2 * ws.xpart_half, s));
+      DLWP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.obuf), (int)kSentinel, 2 * ws.obuf_half, s));
+    }
+  }
   return DLWP_OK;
 }
 template <int ROWS, int G>
 hipError_t trunk_launch_one(const TrunkParams& tp, hipStream_t s) {
   constexpr size_t lds = trunk_lds(ROWS);
-  hipError_t e = allow_lds(fno_trunk_kernel<ROWS, G>, lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((fno_trunk_kernel<ROWS, G>), dim3(tp.S * G), dim3(64 * ROWS), lds, s, tp);
+  if (trunk_ll()) {
+    hipError_t e = allow_lds(fno_trunk_kernel<ROWS, G, true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fno_trunk_kernel<ROWS, G, true>), dim3(tp.S * G), dim3(64 * ROWS), lds, s, tp);
+  } else {
+    hipError_t e = allow_lds(fno_trunk_kernel<ROWS, G, false>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fno_trunk_kernel<ROWS, G, false>), dim3(tp.S * G), dim3(64 * ROWS), lds, s, tp);
+  }
   return hipGetLastError();
 }
 int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, const float* hin, float* hout,
@@ -1996,6 +2142,8 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
     tp.obuf = ws.obuf + (size_t)s0 * nm;
     tp.ctr = ws.ctr + (size_t)s0 * (kCtrStrideBytes / 4);
     tp.epoch = st.epoch; tp.fwd_scale = p->sc.fwd_scale;
+    tp.xpart_par = (long long)ws.xpart_half; tp.obuf_par = (long long)ws.obuf_half; tp.layer0 = st.layers;
+    tp.xcc_tab = ws.ctr + align_up((size_t)B * kCtrStrideBytes, 256) / 4 + (size_t)s0 * 32;
     tp.H = p->H; tp.L = p->L; tp.M1 = p->sc.M1; tp.M2 = p->sc.M2; tp.G = G; tp.sample0 = s0;
     // diagnostics: DLWP_TRUNK_TRACE=<file> dumps per-workgroup phase timestamps of the first few launches
     static const char* trace_path = getenv("DLWP_TRUNK_TRACE");
@@ -2031,6 +2179,7 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
     }
   }
   st.epoch += 2u * (unsigned)p->L;
+  st.layers += (unsigned)p->L;
   return DLWP_OK;
 }
 
