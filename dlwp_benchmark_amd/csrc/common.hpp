@@ -123,9 +123,12 @@ __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
   const float x0 = u[0], x1 = u[1], x2 = u[2], x3 = u[3], x4 = v[0], x5 = v[1], x6 = v[2], x7 = v[3];
   float t0, t1, t2, t3, t4, t5, t6, t7;
   const float umax = DLWP_GELU_UMAX;
-#define DLWP_T(t, x) asm volatile("v_min_f32_e64 %0, |%1|, %2" : "=v"(t) : "v"(x), "s"(umax));
-  DLWP_T(t0, x0) DLWP_T(t2, x2) DLWP_T(t4, x4) DLWP_T(t6, x6) DLWP_T(t1, x1) DLWP_T(t3, x3) DLWP_T(t5, x5) DLWP_T(t7, x7)
-#undef DLWP_T
+  // The FIRST reads of the inputs are plain C, not asm: the inputs are often MFMA results, and a VALU read of a
+  // register an MFMA has just written needs several wait states that hipcc only inserts for instructions it can see --
+  // its hazard recognizer skips inline asm (a fused kernel whose schedule put `v_mfma ... v[64:67]` directly in front
+  // of an asm `v_min_f32 v100, |v64|` computed garbage for exactly those elements).
+  t0 = fminf(fabsf(x0), umax); t2 = fminf(fabsf(x2), umax); t4 = fminf(fabsf(x4), umax); t6 = fminf(fabsf(x6), umax);
+  t1 = fminf(fabsf(x1), umax); t3 = fminf(fabsf(x3), umax); t5 = fminf(fabsf(x5), umax); t7 = fminf(fabsf(x7), umax);
   const f32x2 ta = {t0, t1}, tb = {t2, t3}, tc = {t4, t5}, td = {t6, t7};
   f32x2 pa = {DLWP_GELU_Q8, DLWP_GELU_Q8}, pb = pa, pc = pa, pd = pa;
 #define DLWP_PKSTEP4(cf)                                                                       \

@@ -271,6 +271,113 @@ __global__ __launch_bounds__(256) void pw_mlp2_kernel(const MlpParams p) {
   }
 }
 
+// Lifting MLP of one 64-pixel row segment, bf16x6 layer 2 (see pw_lift_bf16x6_kernel): xs = the input channels
+// (f32x4 per 4-deep k-step, rows 4 s + g), acc2[ot][q][r] = out[co = 16 ot + 4 g + r][pixel 4 j + q].
+// ns = how many of the CIN_STEPS k-steps are populated (uniform; the fused step kernel is instantiated once for
+// CIN_STEPS = 4 and runs any in_channels <= 16 with it).
+template <int CIN_STEPS>
+__device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const float* s_w1, const float* s_b1,
+                                             const u32x4* s_w2, int npair, int lane, const f32x4 (&bias2)[2],
+                                             f32x4 (&acc2)[2][4], int ns = CIN_STEPS) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc2[ot][q] = bias2[ot];
+
+  // Software pipeline over units (tile pair u, pixel-chain pair qp): while the fp32 lanes do layer 1,
+  // GELU and the 3-way bf16 split of unit n (-> B operands bg), the bf16 matrix pipe does layer 2 of
+  // unit n-1.  Three slots per trip, 8 bf16 MFMAs each, fenced so hipcc keeps the interleave (an
+  // in-order wave that issues its MFMAs back to back cannot issue VALU work meanwhile).
+  // (every index into bg / acc2 / xs below is a compile-time constant: runtime-indexed register
+  // arrays go to scratch)
+  u32x4 bg0[2][3], bg1[2][3];   // ping-pong B operands: [q in pair][part]
+  f32x4 a1[2][2];               // [tile in pair][q in pair]
+  u32x4 wa[2][3];               // layer-2 A operands of the unit in flight on the matrix pipe
+  const int nunit = npair * 2;  // unit n = (tile pair n >> 1, chain pair n & 1)
+  auto unit_valu_fc1 = [&](int u, auto qpc) {
+    constexpr int qp = decltype(qpc)::value;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * u + tt;
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) a1[tt][qq] = bb;
+#pragma unroll
+      for (int s = 0; s < CIN_STEPS; ++s) {
+        if (s >= ns) break;
+        const float a = s_w1[(t * ns + s) * 64 + lane];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) a1[tt][qq] = mfma16x16x4(a, xs[s][2 * qp + qq], a1[tt][qq]);
+      }
+    }
+  };
+  auto unit_split = [&](u32x4(&bg)[2][3]) {
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {   // dword i: k-slots 2i, 2i+1 -> tile i/2, registers 2(i%2), 2(i%2)+1
+        unsigned hh, mm, ll;
+        split3_pair(a1[i / 2][qq][2 * (i % 2)], a1[i / 2][qq][2 * (i % 2) + 1], hh, mm, ll);
+        bg[qq][0][i] = hh;
+        bg[qq][1][i] = mm;
+        bg[qq][2][i] = ll;
+      }
+  };
+  auto load_wa = [&](int u) {
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) wa[ot][pp] = s_w2[((u * 3 + pp) * 2 + ot) * 64 + lane];
+  };
+  // 8 of the 24 bf16 MFMAs of a unit: terms {2 slot, 2 slot + 1} of every (ot, q) accumulator,
+  // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+  auto unit_mfma = [&](const u32x4(&bg)[2][3], auto qpc, auto slotc) {
+    constexpr int qp = decltype(qpc)::value, slot = decltype(slotc)::value;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int term = 2 * slot; term < 2 * slot + 2; ++term)
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+          acc2[ot][2 * qp + qq] = mfma16x16x32_bf16(wa[ot][PA[term]], bg[qq][PB[term]], acc2[ot][2 * qp + qq]);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  // one trip: matrix pipe = layer 2 of the previous unit (chain pair QM, operands bgm),
+  //           fp32 lanes  = layer 1 + GELU + split of this unit (chain pair QV -> bgv)
+  auto trip = [&](int u_m, int u_v, const u32x4(&bgm)[2][3], u32x4(&bgv)[2][3], auto qm, auto qv) {
+    load_wa(u_m);
+    unit_valu_fc1(u_v, qv);
+    unit_mfma(bgm, qm, I0{});
+    gelu_erf8(a1[0][0], a1[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    unit_mfma(bgm, qm, I1{});
+    gelu_erf8(a1[1][0], a1[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    unit_mfma(bgm, qm, I2{});
+    unit_split(bgv);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // prologue: unit 0 (tile pair 0, chains 0-1) on the fp32 lanes only
+  unit_valu_fc1(0, I0{});
+  gelu_erf8(a1[0][0], a1[0][1]);
+  gelu_erf8(a1[1][0], a1[1][1]);
+  unit_split(bg0);
+  for (int u = 0; u < npair; ++u) {
+    trip(u, u, bg0, bg1, I0{}, I1{});                            // MFMA unit (u,0) | VALU unit (u,1)
+    if (u + 1 < npair) trip(u, u + 1, bg1, bg0, I1{}, I0{});      // MFMA unit (u,1) | VALU unit (u+1,0)
+  }
+  load_wa(npair - 1);
+  unit_mfma(bg1, I1{}, I0{});
+  unit_mfma(bg1, I1{}, I1{});
+  unit_mfma(bg1, I1{}, I2{});
+  (void)nunit;
+
+}
+
 // ---------------------------------------------------------------------------------------------
 // lifting, bf16x6 variant: out[32] = W2 * gelu(W1 * x + b1) + b2, plus the W-direction DFT of out.
 // Layer 1 (Cin <= 32 -> hid) stays on fp32 MFMA (K is tiny); layer 2 (hid -> 32, K = hid) runs on the
@@ -318,100 +425,7 @@ __global__ __launch_bounds__(512) void pw_lift_bf16x6_kernel(const MlpParams p) 
         xs[s] = cp ? *reinterpret_cast<const f32x4*>(cp + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       f32x4 acc2[2][4];
-#pragma unroll
-      for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc2[ot][q] = bias2[ot];
-
-      // Software pipeline over units (tile pair u, pixel-chain pair qp): while the fp32 lanes do layer 1,
-      // GELU and the 3-way bf16 split of unit n (-> B operands bg), the bf16 matrix pipe does layer 2 of
-      // unit n-1.  Three slots per trip, 8 bf16 MFMAs each, fenced so hipcc keeps the interleave (an
-      // in-order wave that issues its MFMAs back to back cannot issue VALU work meanwhile).
-      // (every index into bg / acc2 / xs below is a compile-time constant: runtime-indexed register
-      // arrays go to scratch)
-      u32x4 bg0[2][3], bg1[2][3];   // ping-pong B operands: [q in pair][part]
-      f32x4 a1[2][2];               // [tile in pair][q in pair]
-      u32x4 wa[2][3];               // layer-2 A operands of the unit in flight on the matrix pipe
-      const int nunit = npair * 2;  // unit n = (tile pair n >> 1, chain pair n & 1)
-      auto unit_valu_fc1 = [&](int u, auto qpc) {
-        constexpr int qp = decltype(qpc)::value;
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int t = 2 * u + tt;
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) a1[tt][qq] = bb;
-#pragma unroll
-          for (int s = 0; s < CIN_STEPS; ++s) {
-            const float a = s_w1[(t * CIN_STEPS + s) * 64 + lane];
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) a1[tt][qq] = mfma16x16x4(a, xs[s][2 * qp + qq], a1[tt][qq]);
-          }
-        }
-      };
-      auto unit_split = [&](u32x4(&bg)[2][3]) {
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {   // dword i: k-slots 2i, 2i+1 -> tile i/2, registers 2(i%2), 2(i%2)+1
-            unsigned hh, mm, ll;
-            split3_pair(a1[i / 2][qq][2 * (i % 2)], a1[i / 2][qq][2 * (i % 2) + 1], hh, mm, ll);
-            bg[qq][0][i] = hh;
-            bg[qq][1][i] = mm;
-            bg[qq][2][i] = ll;
-          }
-      };
-      auto load_wa = [&](int u) {
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp) wa[ot][pp] = s_w2[((u * 3 + pp) * 2 + ot) * 64 + lane];
-      };
-      // 8 of the 24 bf16 MFMAs of a unit: terms {2 slot, 2 slot + 1} of every (ot, q) accumulator,
-      // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-      auto unit_mfma = [&](const u32x4(&bg)[2][3], auto qpc, auto slotc) {
-        constexpr int qp = decltype(qpc)::value, slot = decltype(slotc)::value;
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int term = 2 * slot; term < 2 * slot + 2; ++term)
-#pragma unroll
-          for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq)
-              acc2[ot][2 * qp + qq] = mfma16x16x32_bf16(wa[ot][PA[term]], bg[qq][PB[term]], acc2[ot][2 * qp + qq]);
-      };
-      using I0 = std::integral_constant<int, 0>;
-      using I1 = std::integral_constant<int, 1>;
-      using I2 = std::integral_constant<int, 2>;
-      // one trip: matrix pipe = layer 2 of the previous unit (chain pair QM, operands bgm),
-      //           fp32 lanes  = layer 1 + GELU + split of this unit (chain pair QV -> bgv)
-      auto trip = [&](int u_m, int u_v, const u32x4(&bgm)[2][3], u32x4(&bgv)[2][3], auto qm, auto qv) {
-        load_wa(u_m);
-        unit_valu_fc1(u_v, qv);
-        unit_mfma(bgm, qm, I0{});
-        gelu_erf8(a1[0][0], a1[0][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        unit_mfma(bgm, qm, I1{});
-        gelu_erf8(a1[1][0], a1[1][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        unit_mfma(bgm, qm, I2{});
-        unit_split(bgv);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      // prologue: unit 0 (tile pair 0, chains 0-1) on the fp32 lanes only
-      unit_valu_fc1(0, I0{});
-      gelu_erf8(a1[0][0], a1[0][1]);
-      gelu_erf8(a1[1][0], a1[1][1]);
-      unit_split(bg0);
-      for (int u = 0; u < npair; ++u) {
-        trip(u, u, bg0, bg1, I0{}, I1{});                            // MFMA unit (u,0) | VALU unit (u,1)
-        if (u + 1 < npair) trip(u, u + 1, bg1, bg0, I1{}, I0{});      // MFMA unit (u,1) | VALU unit (u+1,0)
-      }
-      load_wa(npair - 1);
-      unit_mfma(bg1, I1{}, I0{});
-      unit_mfma(bg1, I1{}, I1{});
-      unit_mfma(bg1, I1{}, I2{});
-      (void)nunit;
+      lift_segment<CIN_STEPS>(xs, s_w1, s_b1, s_w2, npair, lane, bias2, acc2);
 
       // epilogue: acc2[ot][q][r] = out[co = 16 ot + 4 g + r][pixel 4 j + q]
 #pragma unroll
@@ -560,6 +574,80 @@ __global__ __launch_bounds__(256) void pw_proj_small_kernel(const MlpParams p) {
   }
 }
 
+// Projection MLP of one 64-pixel row segment (see pw_proj_bf16x6_kernel): bx = the 32 input channels of the
+// lane's 4 pixels as bf16x3 B operands (k order = whatever s_w1 was packed for), po[co][q] = this lane group's
+// partial sum of output co at pixel 4 j + q (to be reduced over the 4 lane groups).
+template <int CO>
+__device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x4* s_w1, const float* s_b1,
+                                             const float* s_w2, int ntile, int lane, float (&po)[CO][4]) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int co = 0; co < CO; ++co)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) po[co][q] = 0.f;
+  auto fc1 = [&](int t, f32x4(&a1)[4]) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
+    u32x4 wa[3];
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) wa[pp] = s_w1[(t * 3 + pp) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a1[q] = mfma_bf16x6(wa, bx[q], bb);
+  };
+  f32x4 a_cur[4], a_nxt[4], g_prev[4], g_new[4];
+  fc1(0, a_cur);
+  fc1(ntile > 1 ? 1 : 0, a_nxt);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) g_prev[q] = a_cur[q];
+  gelu_erf8(g_prev[0], g_prev[1]);
+  gelu_erf8(g_prev[2], g_prev[3]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+  for (int t = 1; t < ntile; ++t) {
+    const int tn = (t + 1 < ntile) ? t + 1 : t;
+    u32x4 wa[3];
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) wa[pp] = s_w1[(tn * 3 + pp) * 64 + lane];
+    f32x4 w2v[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+      w2v[co] = *reinterpret_cast<const f32x4*>(s_w2 + ((t - 1) * CO + co) * 16 + 4 * g);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * tn + 4 * g);
+    // two slots: the bf16 MFMAs of tile tn for two pixel chains (matrix pipe), then GELU of two
+    // accumulator fragments of tile t and the layer-2 FMAs of tile t-1 (fp32 lanes)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a_nxt[2 * i] = mfma_bf16x6(wa, bx[2 * i], bb);
+      a_nxt[2 * i + 1] = mfma_bf16x6(wa, bx[2 * i + 1], bb);
+      g_new[2 * i] = a_cur[2 * i];
+      g_new[2 * i + 1] = a_cur[2 * i + 1];
+      gelu_erf8(g_new[2 * i], g_new[2 * i + 1]);
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int qq = 2 * i; qq < 2 * i + 2; ++qq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) po[co][qq] = fmaf(w2v[co][r], g_prev[qq][r], po[co][qq]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      g_prev[q] = g_new[q];
+      a_cur[q] = a_nxt[q];
+    }
+  }
+  {
+    const int t = ntile - 1;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_w2 + (t * CO + co) * 16 + 4 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) po[co][q] = fmaf(w2[r], g_prev[q][r], po[co][q]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // projection, bf16x6 variant: layer 1 (32 -> hid) runs on the bf16 matrix pipe as six
 // v_mfma_f32_16x16x32_bf16 per (hidden tile, pixel chain) -- K = 32 input channels is exactly one
@@ -608,71 +696,7 @@ __global__ __launch_bounds__(512) void pw_proj_bf16x6_kernel(const MlpParams p) 
           }
       }
       float po[CO][4];
-#pragma unroll
-      for (int co = 0; co < CO; ++co)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) po[co][q] = 0.f;
-      auto fc1 = [&](int t, f32x4(&a1)[4]) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
-        u32x4 wa[3];
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp) wa[pp] = s_w1[(t * 3 + pp) * 64 + lane];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a1[q] = mfma_bf16x6(wa, bx[q], bb);
-      };
-      f32x4 a_cur[4], a_nxt[4], g_prev[4], g_new[4];
-      fc1(0, a_cur);
-      fc1(ntile > 1 ? 1 : 0, a_nxt);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) g_prev[q] = a_cur[q];
-      gelu_erf8(g_prev[0], g_prev[1]);
-      gelu_erf8(g_prev[2], g_prev[3]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
-      for (int t = 1; t < ntile; ++t) {
-        const int tn = (t + 1 < ntile) ? t + 1 : t;
-        u32x4 wa[3];
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp) wa[pp] = s_w1[(tn * 3 + pp) * 64 + lane];
-        f32x4 w2v[CO];
-#pragma unroll
-        for (int co = 0; co < CO; ++co)
-          w2v[co] = *reinterpret_cast<const f32x4*>(s_w2 + ((t - 1) * CO + co) * 16 + 4 * g);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * tn + 4 * g);
-        // two slots: the bf16 MFMAs of tile tn for two pixel chains (matrix pipe), then GELU of two
-        // accumulator fragments of tile t and the layer-2 FMAs of tile t-1 (fp32 lanes)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a_nxt[2 * i] = mfma_bf16x6(wa, bx[2 * i], bb);
-          a_nxt[2 * i + 1] = mfma_bf16x6(wa, bx[2 * i + 1], bb);
-          g_new[2 * i] = a_cur[2 * i];
-          g_new[2 * i + 1] = a_cur[2 * i + 1];
-          gelu_erf8(g_new[2 * i], g_new[2 * i + 1]);
-#pragma unroll
-          for (int co = 0; co < CO; ++co)
-#pragma unroll
-            for (int qq = 2 * i; qq < 2 * i + 2; ++qq)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) po[co][qq] = fmaf(w2v[co][r], g_prev[qq][r], po[co][qq]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          g_prev[q] = g_new[q];
-          a_cur[q] = a_nxt[q];
-        }
-      }
-      {
-        const int t = ntile - 1;
-#pragma unroll
-        for (int co = 0; co < CO; ++co) {
-          const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_w2 + (t * CO + co) * 16 + 4 * g);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) po[co][q] = fmaf(w2[r], g_prev[q][r], po[co][q]);
-        }
-      }
+      proj_segment<CO>(bx, s_w1, s_b1, s_w2, ntile, lane, po);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int co = 0; co < CO; ++co)
@@ -1081,6 +1105,22 @@ struct TrunkParams {
   float fwd_scale;
   int S, H, L, M1, M2, G, sample0;
   unsigned long long* trace;   // diagnostics (DLWP_TRUNK_TRACE): [workgroup][64] s_memrealtime stamps, or null
+  // STEP variant (lifting and projection inside the same launch):
+  ChanTable in;            // the step's input channels (folds _prepare_inputs)
+  int lift_ns, lift_hid;   // populated 4-deep k-steps of the input (<= 4), lifting width (<= 256, multiple of 32)
+  const float* lift_w1p;   // [hid/16][ns][64]
+  const float* lift_b1;    // [hid]
+  const u32x4* lift_w2b;   // [hid/32][3][2][64]
+  const float* lift_b2;    // [32]
+  int proj_hid, proj_co, cout;   // projection width (<= 256), outputs the FMA layer 2 is built for (1, 2, 4), real outputs
+  const u32x4* proj_w1b;   // [hid/16][3][64], k order of the resident activation
+  const float* proj_b1;    // [hid]
+  const float* proj_w2v;   // [hid/16][proj_co][16]
+  const float* proj_b2;    // [16]
+  float* out;              // out + b * out_bstride + co * H * W
+  long long out_bstride;
+  const float* resid;      // or null
+  long long resid_bstride;
 };
 
 __device__ __forceinline__ void trunk_group_barrier(unsigned* ctr, unsigned target, int* s_fail) {
@@ -1153,8 +1193,8 @@ __device__ __forceinline__ void ld4_sc1_x4(const float* base, unsigned o0, unsig
 // itself is the flag: no store drain, no counter round trip, no workgroup barrier on the producer side.
 constexpr unsigned kSentinel = 0x7fc0deadu;
 __device__ __forceinline__ bool has_sentinel(const f32x4& v) {
-  return (__float_as_uint(v[0]) == kSentinel) | (__float_as_uint(v[1]) == kSentinel) |
-         (__float_as_uint(v[2]) == kSentinel) | (__float_as_uint(v[3]) == kSentinel);
+  return __float_as_uint(v[0]) == kSentinel || __float_as_uint(v[1]) == kSentinel ||
+         __float_as_uint(v[2]) == kSentinel || __float_as_uint(v[3]) == kSentinel;
 }
 __device__ __forceinline__ void st4_sc1(const float* base, unsigned off, const f32x4& v) {
   asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" : : "v"(off), "v"(v), "s"(base) : "memory");
@@ -1181,7 +1221,9 @@ __device__ __forceinline__ f32x4 shfl_xor4(f32x4 v, int m) {
 }
 
 // ROWS = grid rows (= waves) per workgroup, G = workgroups per sample = H / ROWS (see trunk_rows() for the choice).
-template <int ROWS, int G, bool LL>
+// STEP: the whole backbone step in this launch -- the lifting MLP produces the resident activation and its first Y row,
+// the projection MLP (+ residual) consumes the last one; their staged weights time-share the transpose tiles' LDS.
+template <int ROWS, int G, bool LL, bool STEP = false>
 __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkParams p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int W = 64, KP = 16, C = kC, NT = 64 * ROWS;
@@ -1230,12 +1272,54 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 
   // resident activation: vv[ot][r] = channel 16 ot + 4 g + r, pixels 4j..4j+3
   f32x4 vv[2][4];
+  if constexpr (STEP) {
+    // ---- lifting: weights staged where the transpose tiles will live (they are not needed before the first DFT)
+    const int ntile_l = p.lift_hid >> 4, npair = ntile_l >> 1;
+    u32x4* l_w2 = reinterpret_cast<u32x4*>(smem);                          // [npair][3][2][64]
+    float* l_w1 = reinterpret_cast<float*>(l_w2 + npair * 6 * 64);         // [ntile][ns][64]
+    float* l_b1 = l_w1 + ntile_l * p.lift_ns * 64;                         // [hid]
+    for (int i = tid; i < npair * 6 * 64; i += NT) l_w2[i] = p.lift_w2b[i];
+    for (int i = tid; i < ntile_l * p.lift_ns * 64; i += NT) l_w1[i] = p.lift_w1p[i];
+    for (int i = tid; i < p.lift_hid; i += NT) l_b1[i] = p.lift_b1[i];
+    f32x4 xs[4];
 #pragma unroll
-  for (int ot = 0; ot < 2; ++ot)
+    for (int s = 0; s < 4; ++s) {
+      const float* cp = s < p.lift_ns ? chan_ptr(p.in, 4 * s + g, gs, (int)HW) : nullptr;
+      xs[s] = cp ? *reinterpret_cast<const f32x4*>(cp + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 bias2[2];
+    bias2[0] = *reinterpret_cast<const f32x4*>(p.lift_b2 + 4 * g);
+    bias2[1] = *reinterpret_cast<const f32x4*>(p.lift_b2 + 16 + 4 * g);
+    lds_barrier();
+    f32x4 acc2[2][4];
+    lift_segment<4>(xs, l_w1, l_b1, l_w2, npair, lane, bias2, acc2, p.lift_ns);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      vv[ot][r] = *reinterpret_cast<const f32x4*>(p.x + ((long long)gs * C + 16 * ot + 4 * g + r) * HW + pix);
-  {
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[ot][r] = f32x4{acc2[ot][0][r], acc2[ot][1][r], acc2[ot][2][r], acc2[ot][3][r]};
+    lds_barrier();   // every wave is done with the lifting weights: the region turns into transpose tiles
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(s_tr + (16 * ot + 4 * g + r) * kTrStride + 4 * j) = vv[ot][r];
+    wave_lds_fence();
+    f32x4 yacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        yacc[ct] = mfma16x16x4(s_tr[(16 * ct + j) * kTrStride + 4 * s + g], s_tt[(4 * s + g) * KP + j], yacc[ct]);
+    wave_lds_fence();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+      *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + j * C + 16 * ct + 4 * g) = yacc[ct];
+  } else {
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        vv[ot][r] = *reinterpret_cast<const f32x4*>(p.x + ((long long)gs * C + 16 * ot + 4 * g + r) * HW + pix);
     const float* yr = p.ybuf + ((long long)gs * H + h) * KP * C;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -1580,6 +1664,56 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
       for (int r = 0; r < 4; ++r) vv[ot][r] = f32x4{nanv, nanv, nanv, nanv};
   }
+  if (STEP && p.proj_hid > 0) {
+    // ---- projection (+ residual): weights staged over the transpose tiles, B operand straight from the registers
+    lds_barrier();
+    const int ntile_p = p.proj_hid >> 4;
+    u32x4* q_w1 = reinterpret_cast<u32x4*>(smem);                          // [ntile][3][64]
+    float* q_b1 = reinterpret_cast<float*>(q_w1 + ntile_p * 3 * 64);       // [hid]
+    float* q_w2 = q_b1 + p.proj_hid;                                       // [ntile][co][16]
+    for (int i = tid; i < ntile_p * 3 * 64; i += NT) q_w1[i] = p.proj_w1b[i];
+    for (int i = tid; i < p.proj_hid; i += NT) q_b1[i] = p.proj_b1[i];
+    for (int i = tid; i < ntile_p * p.proj_co * 16; i += NT) q_w2[i] = p.proj_w2v[i];
+    u32x4 bx[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned hh, mm, ll;
+        split3_pair(vv[i >> 1][2 * (i & 1)][q], vv[i >> 1][2 * (i & 1) + 1][q], hh, mm, ll);
+        bx[q][0][i] = hh;
+        bx[q][1][i] = mm;
+        bx[q][2][i] = ll;
+      }
+    lds_barrier();
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    auto run = [&](auto coc) {
+      constexpr int CO = decltype(coc)::value;
+      float po[CO][4];
+      proj_segment<CO>(bx, q_w1, q_b1, q_w2, ntile_p, lane, po);
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = po[co][q];
+          x += __shfl_xor(x, 16);
+          x += __shfl_xor(x, 32);
+          if (g == co) v[q] = x;
+        }
+    };
+    if (p.proj_co == 1) run(std::integral_constant<int, 1>{});
+    else if (p.proj_co == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 4>{});
+    if (g < p.cout) {
+      const float b2 = p.proj_b2[g];
+      v += f32x4{b2, b2, b2, b2};
+      if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)gs * p.resid_bstride + (long long)g * HW + pix);
+      if (*s_fail) v = f32x4{__uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u),
+                             __uint_as_float(0x7fc00000u)};
+      *reinterpret_cast<f32x4*>(p.out + (long long)gs * p.out_bstride + (long long)g * HW + pix) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -1767,7 +1901,7 @@ struct dlwp_fno2d_plan {
   int cin_steps = 0;
   SpectralCore sc;
   DevBuf lift_w1p, lift_b1, lift_w2p, lift_b2, lift_w2b;
-  DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v, proj_w1b;
+  DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v, proj_w1b, proj_w1bp;   // w1bp: k order of the trunk's resident activation
   int proj_co = 0;  // outputs handled by pw_proj_small_kernel (1, 2 or 4), 0 = generic MFMA path
   std::vector<DevBuf> wt, wsp, sbias, wsb, wsbp;   // wsbp: bf16x3 skip weights in the trunk kernel's k order
 };
@@ -1892,6 +2026,19 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
       pack_a_bf16x3(wb, d->proj_w1, p->hid_p, kC);
       if ((e = p->proj_w1b.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
       if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+      {
+        // fused step kernel: the projection's B operand is the resident activation, k-slot 8g + c' = channel
+        // 16 (c' >> 2) + 4 g + (c' & 3) (same order as the skip weights wsbp)
+        std::vector<float> wperm((size_t)p->hid_p * kC);
+        for (int o = 0; o < p->hid_p; ++o)
+          for (int k = 0; k < kC; ++k) {
+            const int gg = k >> 3, cp = k & 7;
+            wperm[(size_t)o * kC + k] = d->proj_w1[(size_t)o * kC + 16 * (cp >> 2) + 4 * gg + (cp & 3)];
+          }
+        pack_a_bf16x3(wb, wperm.data(), p->hid_p, kC);
+        if ((e = p->proj_w1bp.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+      }
     }
     std::vector<float> b2(16, 0.f);
     for (int i = 0; i < p->cout; ++i) b2[i] = d->proj_b2[i];
@@ -2079,12 +2226,28 @@ bool trunk_eligible(const dlwp_fno2d_plan* p) {
   if (p->W != 64 || p->sc.KP != 16 || p->sc.M1 > 16 || p->L > kTrunkMaxLayers) return false;
   return trunk_rows(p) != 0;
 }
+// Whole step in one launch (STEP variant of the trunk kernel): needs the flag-in-data protocol, 8 rows per workgroup,
+// bf16x6 MLP weights that fit the transpose-tile LDS (widths <= 256, <= 16 input channels) and the FMA layer 2
+// of the projection (<= 4 outputs).  DLWP_FNO_STEP=0 keeps lifting / trunk / projection as three launches.
+bool step_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("DLWP_FNO_STEP");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
 struct TrunkState {
   bool on = false;
   unsigned epoch = 0;    // group barriers already counted since the counters were zeroed
   unsigned layers = 0;   // spectral layers run since the exchange buffers were armed (flag-in-data protocol)
 };
 // Hand-off protocol of the fused trunk: 1 = flag-in-data (default), 0 = counter barriers (DLWP_TRUNK_LL=0).
+bool trunk_ll();
+bool step_eligible(const dlwp_fno2d_plan* p) {
+  return step_enabled() && trunk_eligible(p) && trunk_ll() && trunk_rows(p) == 8 && p->cin_steps <= 4 &&
+         p->hid_l % 32 == 0 && p->hid_l <= 256 && p->hid_p <= 256 && p->proj_co > 0 && p->lift_w2b.p != nullptr &&
+         p->proj_w1bp.p != nullptr;
+}
 bool trunk_ll() {
   static const bool on = [] {
     const char* e = getenv("DLWP_TRUNK_LL");
@@ -2105,6 +2268,14 @@ int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, Tru
   }
   return DLWP_OK;
 }
+template <int G>
+hipError_t step_launch_one(const TrunkParams& tp, hipStream_t s) {
+  constexpr size_t lds = trunk_lds(8);
+  hipError_t e = allow_lds(fno_trunk_kernel<8, G, true, true>, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((fno_trunk_kernel<8, G, true, true>), dim3(tp.S * G), dim3(512), lds, s, tp);
+  return hipGetLastError();
+}
 template <int ROWS, int G>
 hipError_t trunk_launch_one(const TrunkParams& tp, hipStream_t s) {
   constexpr size_t lds = trunk_lds(ROWS);
@@ -2119,8 +2290,16 @@ hipError_t trunk_launch_one(const TrunkParams& tp, hipStream_t s) {
   }
   return hipGetLastError();
 }
+struct StepIO {   // set for the STEP variant: the step's input table, output and residual
+  const ChanTable* in = nullptr;
+  float* out = nullptr;
+  long long out_bstride = 0;
+  const float* resid = nullptr;
+  long long resid_bstride = 0;
+  bool lift_only = false;
+};
 int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, const float* hin, float* hout,
-                     TrunkState& st, hipStream_t s) {
+                     TrunkState& st, hipStream_t s, const StepIO* io = nullptr) {
   const int rows = trunk_rows(p);
   DLWP_REQUIRE(rows > 0, DLWP_ERR_UNSUPPORTED, "fused trunk not available for this plan");
   const int G = p->H / rows;
@@ -2129,7 +2308,7 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
   DLWP_REQUIRE(per_launch > 0, DLWP_ERR_UNSUPPORTED, "a sample needs %d workgroups, more than fit the device", G);
   const size_t nm = (size_t)p->sc.M1 * p->sc.M2 * 64;
   for (int s0 = 0; s0 < B; s0 += per_launch) {
-    TrunkParams tp;
+    TrunkParams tp = {};
     tp.x = hin; tp.y = hout; tp.ybuf = ws.ybuf;
     tp.t = p->sc.t.as<float>(); tp.tt = p->sc.tt.as<float>();
     tp.ef = p->sc.ef.as<float2>(); tp.ei = p->sc.ei.as<float2>(); tp.ck = p->sc.ck.as<float>();
@@ -2156,6 +2335,20 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
       if (tp.S * G <= 1024) tp.trace = trace_buf;
     }
     hipError_t le = hipErrorInvalidValue;
+    if (io) {
+      tp.in = *io->in;
+      tp.lift_ns = p->cin_steps; tp.lift_hid = p->hid_l;
+      tp.lift_w1p = p->lift_w1p.as<float>(); tp.lift_b1 = p->lift_b1.as<float>();
+      tp.lift_w2b = p->lift_w2b.as<u32x4>(); tp.lift_b2 = p->lift_b2.as<float>();
+      tp.proj_hid = p->hid_p; tp.proj_co = p->proj_co; tp.cout = p->cout;
+      if (io->lift_only) { tp.proj_hid = 0; tp.y = hout; }   // diagnostics: the projection stays a launch of its own
+      tp.proj_w1b = p->proj_w1bp.as<u32x4>(); tp.proj_b1 = p->proj_b1.as<float>();
+      tp.proj_w2v = p->proj_w2v.as<float>(); tp.proj_b2 = p->proj_b2.as<float>();
+      tp.out = io->out; tp.out_bstride = io->out_bstride; tp.resid = io->resid; tp.resid_bstride = io->resid_bstride;
+      if (G == 4) le = step_launch_one<4>(tp, s);
+      else if (G == 8) le = step_launch_one<8>(tp, s);
+      else if (G == 16) le = step_launch_one<16>(tp, s);
+    } else
     if (rows == 8 && G == 4) le = trunk_launch_one<8, 4>(tp, s);
     else if (rows == 8 && G == 8) le = trunk_launch_one<8, 8>(tp, s);
     else if (rows == 8 && G == 16) le = trunk_launch_one<8, 16>(tp, s);
@@ -2183,6 +2376,58 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
   return DLWP_OK;
 }
 
+// projection (+ residual) as a launch of its own
+int32_t fno_project(const dlwp_fno2d_plan* p, const float* hin, int B, float* out, long long out_bstride,
+                    const float* resid, long long resid_bstride, hipStream_t s, KernelTimer* timer) {
+  const int nrow = B * p->H;
+  // projection (+ residual)
+  {
+    MlpParams mp;
+    mp.x.seg[0] = ChanSeg{hin, (long long)kC * p->H * p->W, kC, 0};
+    for (int i = 1; i < 4; ++i) mp.x.seg[i] = ChanSeg{nullptr, 0, 0, 0};
+    mp.hid = p->hid_p; mp.cout = p->cout;
+    mp.w1p = p->proj_w1p.as<float>(); mp.b1 = p->proj_b1.as<float>();
+    mp.w2p = p->proj_w2p.as<float>(); mp.b2 = p->proj_b2.as<float>();
+    mp.out = out; mp.out_bstride = out_bstride; mp.resid = resid; mp.resid_bstride = resid_bstride;
+    mp.ybuf = nullptr; mp.tt = nullptr;
+    mp.B = B; mp.H = p->H; mp.W = p->W;
+    const int nt = p->hid_p / 16;
+    const size_t lds = ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * 4 * 1 * 64) * 4;
+    const int grid = grid_rows(nrow, 4);
+    if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::PROJ));
+    if (p->proj_co > 0) {
+      mp.w2p = p->proj_w2v.as<float>();
+      const bool bf = use_bf16x6();
+      if (bf) mp.w1p = p->proj_w1b.as<float>();
+      const size_t lds2 = bf ? ((size_t)nt * 3 * 64 * 4 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4
+                             : ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4;
+#define DLWP_LAUNCH_PROJ(CO_, RES_)                                                                     \
+  do {                                                                                                  \
+    if (bf) {                                                                                           \
+      DLWP_HIP_CHECK(allow_lds(pw_proj_bf16x6_kernel<CO_, RES_>, lds2));                                \
+      hipLaunchKernelGGL((pw_proj_bf16x6_kernel<CO_, RES_>), dim3((grid + 1) / 2), dim3(512), lds2, s, mp); \
+    } else {                                                                                            \
+      DLWP_HIP_CHECK(allow_lds(pw_proj_small_kernel<CO_, RES_>, lds2));                                 \
+      hipLaunchKernelGGL((pw_proj_small_kernel<CO_, RES_>), dim3(grid), dim3(256), lds2, s, mp);        \
+    }                                                                                                   \
+  } while (0)
+      if (p->proj_co == 1) { if (resid) DLWP_LAUNCH_PROJ(1, true); else DLWP_LAUNCH_PROJ(1, false); }
+      else if (p->proj_co == 2) { if (resid) DLWP_LAUNCH_PROJ(2, true); else DLWP_LAUNCH_PROJ(2, false); }
+      else { if (resid) DLWP_LAUNCH_PROJ(4, true); else DLWP_LAUNCH_PROJ(4, false); }
+#undef DLWP_LAUNCH_PROJ
+    } else if (resid) {
+      DLWP_HIP_CHECK(allow_lds(pw_mlp2_kernel<8, 1, 16, false, true>, lds));
+      hipLaunchKernelGGL((pw_mlp2_kernel<8, 1, 16, false, true>), dim3(grid), dim3(256), lds, s, mp);
+    } else {
+      DLWP_HIP_CHECK(allow_lds(pw_mlp2_kernel<8, 1, 16, false, false>, lds));
+      hipLaunchKernelGGL((pw_mlp2_kernel<8, 1, 16, false, false>), dim3(grid), dim3(256), lds, s, mp);
+    }
+    DLWP_HIP_CHECK(hipGetLastError());
+    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::PROJ));
+  }
+  return DLWP_OK;
+}
+
 // one backbone step: x (channel table) -> out (+ resid)
 int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const FnoWorkspace& ws, float* out,
                  long long out_bstride, const float* resid, long long resid_bstride, hipStream_t s,
@@ -2191,6 +2436,19 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
   if (timer) {  // calibration: an empty bracket measures what the event pair itself adds
     DLWP_HIP_CHECK(timer->begin(KernelTimer::EMPTY));
     DLWP_HIP_CHECK(timer->end(KernelTimer::EMPTY));
+  }
+  if (trunk && trunk->on && step_eligible(p)) {
+    // the whole step in ONE launch (reported in the LAYER class; LIFT / MODES / PROJ stay empty)
+    StepIO io;
+    io.in = &xt; io.out = out; io.out_bstride = out_bstride; io.resid = resid; io.resid_bstride = resid_bstride;
+    if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::LAYER));
+    static const bool lift_only = [] { const char* e = getenv("DLWP_STEP_LIFT_ONLY"); return e && atoi(e) != 0; }();
+    io.lift_only = lift_only;
+    const int32_t rc = launch_trunk(p, ws, B, nullptr, lift_only ? ws.h1 : nullptr, *trunk, s, &io);
+    if (rc != DLWP_OK) return rc;
+    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::LAYER));
+    if (!lift_only) return DLWP_OK;
+    return fno_project(p, ws.h1, B, out, out_bstride, resid, resid_bstride, s, timer);
   }
   // lifting (+ W-direction DFT of its output)
   {
@@ -2253,52 +2511,7 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::LAYER));
     float* t = hin; hin = hout; hout = t;
   }
-  // projection (+ residual)
-  {
-    MlpParams mp;
-    mp.x.seg[0] = ChanSeg{hin, (long long)kC * p->H * p->W, kC, 0};
-    for (int i = 1; i < 4; ++i) mp.x.seg[i] = ChanSeg{nullptr, 0, 0, 0};
-    mp.hid = p->hid_p; mp.cout = p->cout;
-    mp.w1p = p->proj_w1p.as<float>(); mp.b1 = p->proj_b1.as<float>();
-    mp.w2p = p->proj_w2p.as<float>(); mp.b2 = p->proj_b2.as<float>();
-    mp.out = out; mp.out_bstride = out_bstride; mp.resid = resid; mp.resid_bstride = resid_bstride;
-    mp.ybuf = nullptr; mp.tt = nullptr;
-    mp.B = B; mp.H = p->H; mp.W = p->W;
-    const int nt = p->hid_p / 16;
-    const size_t lds = ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * 4 * 1 * 64) * 4;
-    const int grid = grid_rows(nrow, 4);
-    if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::PROJ));
-    if (p->proj_co > 0) {
-      mp.w2p = p->proj_w2v.as<float>();
-      const bool bf = use_bf16x6();
-      if (bf) mp.w1p = p->proj_w1b.as<float>();
-      const size_t lds2 = bf ? ((size_t)nt * 3 * 64 * 4 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4
-                             : ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4;
-#define DLWP_LAUNCH_PROJ(CO_, RES_)                                                                     \
-  do {                                                                                                  \
-    if (bf) {                                                                                           \
-      DLWP_HIP_CHECK(allow_lds(pw_proj_bf16x6_kernel<CO_, RES_>, lds2));                                \
-      hipLaunchKernelGGL((pw_proj_bf16x6_kernel<CO_, RES_>), dim3((grid + 1) / 2), dim3(512), lds2, s, mp); \
-    } else {                                                                                            \
-      DLWP_HIP_CHECK(allow_lds(pw_proj_small_kernel<CO_, RES_>, lds2));                                 \
-      hipLaunchKernelGGL((pw_proj_small_kernel<CO_, RES_>), dim3(grid), dim3(256), lds2, s, mp);        \
-    }                                                                                                   \
-  } while (0)
-      if (p->proj_co == 1) { if (resid) DLWP_LAUNCH_PROJ(1, true); else DLWP_LAUNCH_PROJ(1, false); }
-      else if (p->proj_co == 2) { if (resid) DLWP_LAUNCH_PROJ(2, true); else DLWP_LAUNCH_PROJ(2, false); }
-      else { if (resid) DLWP_LAUNCH_PROJ(4, true); else DLWP_LAUNCH_PROJ(4, false); }
-#undef DLWP_LAUNCH_PROJ
-    } else if (resid) {
-      DLWP_HIP_CHECK(allow_lds(pw_mlp2_kernel<8, 1, 16, false, true>, lds));
-      hipLaunchKernelGGL((pw_mlp2_kernel<8, 1, 16, false, true>), dim3(grid), dim3(256), lds, s, mp);
-    } else {
-      DLWP_HIP_CHECK(allow_lds(pw_mlp2_kernel<8, 1, 16, false, false>, lds));
-      hipLaunchKernelGGL((pw_mlp2_kernel<8, 1, 16, false, false>), dim3(grid), dim3(256), lds, s, mp);
-    }
-    DLWP_HIP_CHECK(hipGetLastError());
-    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::PROJ));
-  }
-  return DLWP_OK;
+  return fno_project(p, hin, B, out, out_bstride, resid, resid_bstride, s, timer);
 }
 }  // namespace
 
