@@ -260,6 +260,11 @@ def main():
             if whole_step:   # + the lifting and projection MLPs' own bytes / flops
                 lay_bytes += work["lift"]["bytes"] + work["proj"]["bytes"]
                 lay_flops += work["lift"]["flops"] + work["proj"]["flops"]
+                # persistent form: one launch runs every step of the rollout
+                steps_per_launch = max(1, K_roll // max(lay["launches_per_rollout"], 1))
+                lay_bytes *= steps_per_launch
+                lay_flops *= steps_per_launch
+                lay["rollout_steps_per_launch"] = steps_per_launch
             lay["GBps"] = lay_bytes / (lay["avg_ms"] * 1e-3) / 1e9
             lay["TFLOPs"] = lay_flops / (lay["avg_ms"] * 1e-3) / 1e12
             lay["spectral_layers_per_launch"] = nl

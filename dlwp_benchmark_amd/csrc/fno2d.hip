@@ -1121,6 +1121,13 @@ struct TrunkParams {
   long long out_bstride;
   const float* resid;      // or null
   long long resid_bstride;
+  // several steps in this launch (n_steps > 1): the per-step tables above are rebuilt on the device from
+  const float* r_const;    // constants  [B, 1, n_const, H, W] or null
+  const float* r_presc;    // prescribed [B, T, n_presc, H, W] or null
+  const float* r_prog;     // prognostic [B, T, n_prog, H, W]
+  float* r_out;            // out        [B, T - ctx, n_prog, H, W]
+  int r_nconst, r_npresc, r_nprog, r_T, r_ctx, r_t0;   // first time index of this launch (ctx + step_begin)
+  int n_steps;             // 0 / 1: one step described by in / out / resid
 };
 
 __device__ __forceinline__ void trunk_group_barrier(unsigned* ctr, unsigned target, int* s_fail) {
@@ -1221,6 +1228,32 @@ __device__ __forceinline__ f32x4 shfl_xor4(f32x4 v, int m) {
 }
 
 // ROWS = grid rows (= waves) per workgroup, G = workgroups per sample = H / ROWS (see trunk_rows() for the choice).
+// Input table / output slot / residual of rollout step t, exactly as fno_rollout_impl builds them on the host
+// (fno.py:49-62, :79-103): window of constants, prescribed[t-ctx:t], prognostic frames still taken from the input,
+// then frames already produced.
+__device__ __forceinline__ void rollout_step_io(const TrunkParams& p, int t, long long HW, ChanTable& in, float*& out,
+                                                long long& out_bs, const float*& resid, long long& resid_bs) {
+  const int T = p.r_T, ctx = p.r_ctx, To = T - ctx;
+  const long long prog_bs = (long long)T * p.r_nprog * HW;
+  out_bs = (long long)To * p.r_nprog * HW;
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) in.seg[i] = ChanSeg{nullptr, 0, 0, 0};
+  if (p.r_nconst) in.seg[k++] = ChanSeg{p.r_const, (long long)p.r_nconst * HW, p.r_nconst, 0};
+  if (p.r_npresc)
+    in.seg[k++] = ChanSeg{p.r_presc + (long long)(t - ctx) * p.r_npresc * HW, (long long)T * p.r_npresc * HW, p.r_npresc * ctx, 0};
+  const int f0 = t - ctx;
+  const int n_in = (f0 < ctx) ? (ctx - f0 < ctx ? ctx - f0 : ctx) : 0;
+  if (n_in > 0) in.seg[k++] = ChanSeg{p.r_prog + (long long)f0 * p.r_nprog * HW, prog_bs, p.r_nprog * n_in, 0};
+  if (ctx - n_in > 0) {
+    const int fo = f0 + n_in - ctx;
+    in.seg[k++] = ChanSeg{p.r_out + (long long)fo * p.r_nprog * HW, out_bs, p.r_nprog * (ctx - n_in), 0};
+  }
+  if (t - 1 < ctx) { resid = p.r_prog + (long long)(t - 1) * p.r_nprog * HW; resid_bs = prog_bs; }
+  else { resid = p.r_out + (long long)(t - 1 - ctx) * p.r_nprog * HW; resid_bs = out_bs; }
+  out = p.r_out + (long long)(t - ctx) * p.r_nprog * HW;
+}
+
 // STEP: the whole backbone step in this launch -- the lifting MLP produces the resident activation and its first Y row,
 // the projection MLP (+ residual) consumes the last one; their staged weights time-share the transpose tiles' LDS.
 template <int ROWS, int G, bool LL, bool STEP = false>
@@ -1270,6 +1303,15 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     s_tt[i] = p.tt[i];
   }
 
+  // STEP: the steps of this launch (one, or a whole rollout range without the host in the loop: a row's next input
+  // is what the same wave has just written, so steps need no synchronisation beyond the spectrum hand-offs)
+  const int n_steps = (STEP && p.n_steps > 1) ? p.n_steps : 1;
+  for (int st = 0; st < n_steps; ++st) {
+  ChanTable in = p.in;
+  float* out_p = p.out;
+  long long out_bs = p.out_bstride, resid_bs = p.resid_bstride;
+  const float* resid_p = p.resid;
+  if (STEP && p.n_steps > 1) rollout_step_io(p, p.r_t0 + st, HW, in, out_p, out_bs, resid_p, resid_bs);
   // resident activation: vv[ot][r] = channel 16 ot + 4 g + r, pixels 4j..4j+3
   f32x4 vv[2][4];
   if constexpr (STEP) {
@@ -1284,7 +1326,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     f32x4 xs[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const float* cp = s < p.lift_ns ? chan_ptr(p.in, 4 * s + g, gs, (int)HW) : nullptr;
+      const float* cp = s < p.lift_ns ? chan_ptr(in, 4 * s + g, gs, (int)HW) : nullptr;
       xs[s] = cp ? *reinterpret_cast<const f32x4*>(cp + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     f32x4 bias2[2];
@@ -1363,13 +1405,13 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   DLWP_STAMP();
 
   for (int l = 0; l < p.L; ++l) {
-    const int par = LL ? (int)((p.layer0 + (unsigned)l) & 1u) : 0;
+    const int par = LL ? (int)((p.layer0 + (unsigned)(st * p.L + l)) & 1u) : 0;
     float* xp_mine = xp_mine0 + par * p.xpart_par;
     const float* xp_grp = xp_grp0 + par * p.xpart_par;
     float* ob = ob0 + par * p.obuf_par;
     float* ob_other = ob0 + (par ^ 1) * p.obuf_par;
     if (LL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's re-arming stores of the previous layer are done
-    const bool fast = LL && l > 0 && (*s_fast != 0);
+    const bool fast = LL && (l > 0 || st > 0) && (*s_fast != 0);
     // operands that do not depend on data are requested before the barriers: the skip weights / bias of the row
     // phase and the weights of this wave's first two modes
     u32x4 wb[2][3];
@@ -1569,7 +1611,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
             ld4_sc1_x4(ob, o[0], o[1], o[2], o[3], v0, v1, v2, v3);
           }
         }
-        if (LL && l == 0 && wave == 0 && ky == 0) {
+        if (LL && l == 0 && st == 0 && wave == 0 && ky == 0) {
           // O of layer 0 has arrived, so every workgroup of the group has run and published its XCC id: does the
           // whole group share this XCD?  (decides the store flavour of all later exchanges, see st_xchg)
           const unsigned want = (p.layer0 + 1u) << 4;
@@ -1707,18 +1749,26 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     if (g < p.cout) {
       const float b2 = p.proj_b2[g];
       v += f32x4{b2, b2, b2, b2};
-      if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)gs * p.resid_bstride + (long long)g * HW + pix);
+      if (resid_p) v += *reinterpret_cast<const f32x4*>(resid_p + (long long)gs * resid_bs + (long long)g * HW + pix);
       if (*s_fail) v = f32x4{__uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u),
                              __uint_as_float(0x7fc00000u)};
-      *reinterpret_cast<f32x4*>(p.out + (long long)gs * p.out_bstride + (long long)g * HW + pix) = v;
+      *reinterpret_cast<f32x4*>(out_p + (long long)gs * out_bs + (long long)g * HW + pix) = v;
     }
-    return;
+    if (st + 1 < n_steps) {
+      // the next step's input rows are the ones this wave has just written: drain the stores, drop any L1 copy,
+      // and let every wave finish with the projection weights before the lifting weights overwrite them
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      lds_barrier();
+    }
+    continue;
   }
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       *reinterpret_cast<f32x4*>(p.y + ((long long)gs * C + 16 * ot + 4 * g + r) * HW + pix) = vv[ot][r];
+  }   // steps
 }
 
 // Spectral weights [Ci][Co][R][K][2] (reference / PyTorch layout, device) -> the kernels' [K][R][Ci'][Co'] float2.
@@ -2243,6 +2293,14 @@ struct TrunkState {
 };
 // Hand-off protocol of the fused trunk: 1 = flag-in-data (default), 0 = counter barriers (DLWP_TRUNK_LL=0).
 bool trunk_ll();
+// DLWP_FNO_PERSISTENT=0: one launch per step instead of one per rollout range
+bool rollout_persistent() {
+  static const bool on = [] {
+    const char* e = getenv("DLWP_FNO_PERSISTENT");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
 bool step_eligible(const dlwp_fno2d_plan* p) {
   return step_enabled() && trunk_eligible(p) && trunk_ll() && trunk_rows(p) == 8 && p->cin_steps <= 4 &&
          p->hid_l % 32 == 0 && p->hid_l <= 256 && p->hid_p <= 256 && p->proj_co > 0 && p->lift_w2b.p != nullptr &&
@@ -2297,6 +2355,12 @@ struct StepIO {   // set for the STEP variant: the step's input table, output an
   const float* resid = nullptr;
   long long resid_bstride = 0;
   bool lift_only = false;
+  // n_steps > 1: a whole range of rollout steps in one launch, tables rebuilt on the device
+  int n_steps = 1, t0 = 0, n_const = 0, n_presc = 0, n_prog = 0, T = 0, ctx = 0;
+  const float* constants = nullptr;
+  const float* prescribed = nullptr;
+  const float* prognostic = nullptr;
+  float* rollout_out = nullptr;
 };
 int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, const float* hin, float* hout,
                      TrunkState& st, hipStream_t s, const StepIO* io = nullptr) {
@@ -2345,6 +2409,12 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
       tp.proj_w1b = p->proj_w1bp.as<u32x4>(); tp.proj_b1 = p->proj_b1.as<float>();
       tp.proj_w2v = p->proj_w2v.as<float>(); tp.proj_b2 = p->proj_b2.as<float>();
       tp.out = io->out; tp.out_bstride = io->out_bstride; tp.resid = io->resid; tp.resid_bstride = io->resid_bstride;
+      tp.n_steps = io->n_steps;
+      if (io->n_steps > 1) {
+        tp.r_const = io->constants; tp.r_presc = io->prescribed; tp.r_prog = io->prognostic; tp.r_out = io->rollout_out;
+        tp.r_nconst = io->n_const; tp.r_npresc = io->n_presc; tp.r_nprog = io->n_prog; tp.r_T = io->T; tp.r_ctx = io->ctx;
+        tp.r_t0 = io->t0;
+      }
       if (G == 4) le = step_launch_one<4>(tp, s);
       else if (G == 8) le = step_launch_one<8>(tp, s);
       else if (G == 16) le = step_launch_one<16>(tp, s);
@@ -2371,8 +2441,9 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
       ++traced;
     }
   }
-  st.epoch += 2u * (unsigned)p->L;
-  st.layers += (unsigned)p->L;
+  const unsigned steps = (io && io->n_steps > 1) ? (unsigned)io->n_steps : 1u;
+  st.epoch += 2u * (unsigned)p->L * steps;
+  st.layers += (unsigned)p->L * steps;
   return DLWP_OK;
 }
 
@@ -2578,6 +2649,25 @@ static int32_t fno_rollout_impl(const dlwp_fno2d_plan* plan, const float* consta
   {
     const int32_t rc0 = trunk_begin(plan, ws, batch, trunk, s);
     if (rc0 != DLWP_OK) return rc0;
+  }
+  if (trunk.on && step_eligible(plan) && rollout_persistent() && step_end - step_begin > 1) {
+    // the whole range in ONE launch: no host in the loop, no launch gaps (reported in the LAYER class)
+    ChanTable none;
+    for (int i = 0; i < 4; ++i) none.seg[i] = ChanSeg{nullptr, 0, 0, 0};
+    StepIO io;
+    io.in = &none;
+    io.n_steps = step_end - step_begin; io.t0 = ctx + step_begin;
+    io.n_const = n_const; io.n_presc = n_presc; io.n_prog = n_prog; io.T = T; io.ctx = ctx;
+    io.constants = constants; io.prescribed = prescribed; io.prognostic = prognostic; io.rollout_out = out;
+    if (timer) {
+      DLWP_HIP_CHECK(timer->begin(KernelTimer::EMPTY));
+      DLWP_HIP_CHECK(timer->end(KernelTimer::EMPTY));
+      DLWP_HIP_CHECK(timer->begin(KernelTimer::LAYER));
+    }
+    const int32_t rc = launch_trunk(plan, ws, batch, nullptr, nullptr, trunk, s, &io);
+    if (rc != DLWP_OK) return rc;
+    if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::LAYER));
+    return DLWP_OK;
   }
   for (int t = ctx + step_begin; t < ctx + step_end; ++t) {
     // x_t = cat(constants[:,0], prescribed[:, t-ctx:t], prognostic window)   (fno.py:49-62, :79-100)
