@@ -1270,6 +1270,8 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   float* s_tt = s_t + KP * W;                             // [64][16]      TT (forward W-DFT twiddles)
   int* s_fail = reinterpret_cast<int*>(s_tt + W * KP);
   int* s_fast = s_fail + 1;                               // LL: the sample's group shares one XCD (found in layer 0)
+  float2* s_ef = reinterpret_cast<float2*>(s_fail + 4);   // [16][ROWS]  EF rows of this workgroup's grid rows (0 beyond M1)
+  float2* s_ei = s_ef + 16 * ROWS;                        // [16][ROWS]  EI likewise
   const int H = p.H, M1 = p.M1, M2 = p.M2, NM = M1 * M2;
   int sample, member;
   {
@@ -1302,11 +1304,27 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     s_t[i] = p.t[i];
     s_tt[i] = p.tt[i];
   }
+  for (int i = tid; i < 16 * ROWS; i += NT) {   // the persistent form re-derives its MFMA operands from these every step
+    const int r = i / ROWS, hl = i % ROWS;
+    s_ef[i] = r < M1 ? p.ef[r * H + member * ROWS + hl] : float2{0.f, 0.f};
+    s_ei[i] = r < M1 ? p.ei[r * H + member * ROWS + hl] : float2{0.f, 0.f};
+  }
+  lds_barrier();   // the tables above are read by every wave right away
 
   // STEP: the steps of this launch (one, or a whole rollout range without the host in the loop: a row's next input
   // is what the same wave has just written, so steps need no synchronisation beyond the spectrum hand-offs)
+  int n_stamp = 0;
   const int n_steps = (STEP && p.n_steps > 1) ? p.n_steps : 1;
   for (int st = 0; st < n_steps; ++st) {
+  // Everything lane-dependent is re-derived from an OPAQUE copy of the thread index inside the step loop: otherwise
+  // hipcc hoists the step-invariant address arithmetic and MFMA operands of all phases out of the loop, keeps them
+  // live across the lifting MLP and spills ~160 VGPRs per lane to scratch (664 bytes/lane in the first version).
+  int tid_o = threadIdx.x;
+  asm volatile("" : "+v"(tid_o));
+  const int tid = tid_o, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  float* s_tr = smem + wave * (C * kTrStride);
+  const int h = member * ROWS + wave;
+  const long long pix = (long long)h * W + 4 * j;
   ChanTable in = p.in;
   float* out_p = p.out;
   long long out_bs = p.out_bstride, resid_bs = p.resid_bstride;
@@ -1356,6 +1374,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
       *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + j * C + 16 * ct + 4 * g) = yacc[ct];
+    if (p.trace && tid == 0 && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
   } else {
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -1375,7 +1394,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   for (int s = 0; s < KS1; ++s) {
     const int hl = 2 * s + (g >> 1);
     float2 e = {0.f, 0.f};
-    if (j < M1) e = p.ef[j * H + member * ROWS + hl];
+    if (j < M1) e = s_ef[j * ROWS + hl];
     a_re[s] = (g & 1) ? -e.y : e.x;
     a_im[s] = (g & 1) ? e.x : e.y;
   }
@@ -1384,7 +1403,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   for (int s = 0; s < 8; ++s) {
     const int r = 2 * s + (g >> 1);
     float2 e = {0.f, 0.f};
-    if (r < M1 && (j >> 1) < ROWS) e = p.ei[r * H + member * ROWS + (j >> 1)];
+    if (r < M1 && (j >> 1) < ROWS) e = s_ei[r * ROWS + (j >> 1)];
     a3[s] = (j & 1) ? ((g & 1) ? e.x : e.y) : ((g & 1) ? -e.y : e.x);
   }
   const int ks3 = (2 * M1 + 3) / 4;
@@ -1397,7 +1416,6 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   float* ob0 = p.obuf + (long long)sample * NM * 64;
   unsigned target = p.epoch * (unsigned)G;
 
-  int n_stamp = 0;
 #define DLWP_STAMP()                                                                                   \
   do {                                                                                                 \
     if (p.trace && tid == 0 && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime(); \
@@ -1754,6 +1772,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
                              __uint_as_float(0x7fc00000u)};
       *reinterpret_cast<f32x4*>(out_p + (long long)gs * out_bs + (long long)g * HW + pix) = v;
     }
+    if (p.trace && tid == 0 && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
     if (st + 1 < n_steps) {
       // the next step's input rows are the ones this wave has just written: drain the stores, drop any L1 copy,
       // and let every wave finish with the projection weights before the lifting weights overwrite them
@@ -2247,7 +2266,8 @@ bool trunk_enabled() {
   return on;
 }
 constexpr size_t trunk_lds(int rows) {
-  return ((size_t)rows * kC * kTrStride + rows * kSyStride + rows * 16 * kC + rows * 128 + 2 * 16 * 64 + 4) * sizeof(float);
+  return ((size_t)rows * kC * kTrStride + rows * kSyStride + rows * 16 * kC + rows * 128 + 2 * 16 * 64 + 4 + 2 * 2 * 16 * rows) *
+         sizeof(float);
 }
 // rows (= waves) per workgroup.  8 = one workgroup per CU (default).  4 puts two workgroups on a CU (2 x 61 KB of
 // LDS, 2 x 4 waves x 256 VGPRs) so that one can compute rows while the other sits in a group barrier -- measured
