@@ -26,7 +26,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-constexpr int CI_CHUNK = 8, CO_CHUNK = 16;
+constexpr int CI_CHUNK = 8;
 
 struct Params {
   const float* x0; int c0;   // first input segment [B][c0][H][W]
@@ -43,7 +43,9 @@ struct Params {
 
 // TH x TW output tile per workgroup (TH*TW threads); blockIdx.z selects the 16-channel output chunk, so the deep,
 // low-resolution layers of a U-Net (8x8 maps with 64 channels) still spread over enough workgroups.
-template <int TH, int TW>
+// CO_CHUNK output channels per thread: 16 for big maps; 4 when the map is small, so that a layer still spreads over
+// >= 512 workgroups (an 8x8 map with 64 channels took 117 us as 128 one-wave workgroups of 16 channels each).
+template <int TH, int TW, int CO_CHUNK>
 __global__ __launch_bounds__(TH * TW) void conv3x3_cyl_kernel(const Params p) {
   constexpr int NT = TH * TW;
   __shared__ float s_in[CI_CHUNK][TH + 2][TW + 2];
@@ -180,15 +182,22 @@ __global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __rest
 
 using namespace dlwp;
 
-static void launch_conv3x3(const conv::Params& p, hipStream_t s) {
-  const int zc = (p.Cout + conv::CO_CHUNK - 1) / conv::CO_CHUNK;
+template <int CO>
+static void launch_conv3x3_co(const conv::Params& p, hipStream_t s) {
+  const int zc = (p.Cout + CO - 1) / CO;
   auto tiles = [&](int th, int tw) { return ((p.W + tw - 1) / tw) * ((p.H + th - 1) / th); };
   if (p.W >= 32)
-    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<8, 32>), dim3(tiles(8, 32), p.B, zc), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<8, 32, CO>), dim3(tiles(8, 32), p.B, zc), dim3(256), 0, s, p);
   else if (p.W >= 16)
-    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<16, 16>), dim3(tiles(16, 16), p.B, zc), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<16, 16, CO>), dim3(tiles(16, 16), p.B, zc), dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<8, 8>), dim3(tiles(8, 8), p.B, zc), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((conv::conv3x3_cyl_kernel<8, 8, CO>), dim3(tiles(8, 8), p.B, zc), dim3(64), 0, s, p);
+}
+static void launch_conv3x3(const conv::Params& p, hipStream_t s) {
+  const int th = p.W >= 32 ? 8 : (p.W >= 16 ? 16 : 8), tw = p.W >= 32 ? 32 : (p.W >= 16 ? 16 : 8);
+  const long long wgs16 = (long long)((p.W + tw - 1) / tw) * ((p.H + th - 1) / th) * p.B * ((p.Cout + 15) / 16);
+  if (wgs16 >= 1024) launch_conv3x3_co<16>(p, s);
+  else launch_conv3x3_co<4>(p, s);
 }
 
 extern "C" int32_t dlwp_conv3x3_cyl_f32(const float* x0, int32_t c0, const float* x1, int32_t c1, const float* weight,

@@ -20,6 +20,24 @@ class HipBackbone(torch.nn.Module):
     def __init__(self):
         super().__init__()
         self._ws = None
+        self.step_graphs = False     # replay one_step as a HIP graph (launch-bound backbones), see graphs.py
+        self._graphed = None
+
+    def set_step_graphs(self, on: bool = True):
+        """Capture `one_step` into a HIP graph and replay it per rollout step (eval mode only)."""
+        self.step_graphs = bool(on)
+        self._graphed = None
+        return self
+
+    def _step_fn(self):
+        if not self.step_graphs or self.training:
+            return self.one_step
+        key = tuple(p.data_ptr() for p in self.parameters())
+        if self._graphed is None or self._graphed[0] != key:
+            from ..graphs import GraphedStep
+
+            self._graphed = (key, GraphedStep(self.one_step))
+        return self._graphed[1]
 
     def _check_inputs(self, constants, prescribed, prognostic):
         if prognostic is None:

@@ -120,7 +120,7 @@ class FourCastNet(HipBackbone):
             b, self.out_chans, self.h * p1, self.w * p2)
 
     def rollout_into(self, out, constants, prescribed, prognostic, step_begin=0, step_end=-1):
-        return rollout_into(self.one_step, self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)
+        return rollout_into(self._step_fn(), self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)
 
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:

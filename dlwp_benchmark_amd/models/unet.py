@@ -253,7 +253,7 @@ class UNet(HipBackbone):
         return self.decoder(x=enc[-1], skips=enc[::-1])
 
     def rollout_into(self, out, constants, prescribed, prognostic, step_begin=0, step_end=-1):
-        return rollout_into(self.one_step, self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)
+        return rollout_into(self._step_fn(), self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)
 
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
@@ -304,7 +304,7 @@ class UNetHPX(UNet):
             # face-folded working layout [(B F), T, C, H, W]: the generic rollout then runs unchanged
             fold5 = lambda t: t.permute(0, 3, 1, 2, 4, 5).reshape(b * f, t.shape[1], t.shape[2], h, w).float().contiguous()
             out = torch.empty(b * f, t_total - ctx, cg, h, w, device=prognostic.device, dtype=torch.float32)
-            rollout_into(self.one_step, ctx, out, fold5(constants) if constants is not None else None,
+            rollout_into(self._step_fn(), ctx, out, fold5(constants) if constants is not None else None,
                          fold5(prescribed) if prescribed is not None else None, fold5(prognostic))
             return out.reshape(b, f, t_total - ctx, cg, h, w).permute(0, 2, 3, 1, 4, 5).contiguous()
 

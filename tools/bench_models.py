@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--attn-bf16", action="store_true", help="bf16 MFMA window attention (Swin / Pangu)")
+    ap.add_argument("--graphs", action="store_true", help="replay every backbone step as a HIP graph")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name, (cls, cfg, batch, steps, (h, w)) in CONFIGS.items():
@@ -50,6 +51,8 @@ def main():
         model = cls(**cfg)
         fill_state_dict(model, gain=0.7)
         model = model.to(dev).eval()
+        if args.graphs:
+            model.set_step_graphs(True)
         if args.attn_bf16 and hasattr(model, "set_attention_precision"):
             model.set_attention_precision("bf16")
         if cfg["constant_channels"] == 0:
@@ -65,7 +68,7 @@ def main():
             out = model(constants=c, prescribed=p, prognostic=g)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.reps
-        res = {"config": name, "attention": "bf16" if args.attn_bf16 else "fp32", "batch": batch, "rollout_steps": steps, "ms_per_rollout": dt * 1e3,
+        res = {"config": name, "graphs": bool(args.graphs), "attention": "bf16" if args.attn_bf16 else "fp32", "batch": batch, "rollout_steps": steps, "ms_per_rollout": dt * 1e3,
                "ms_per_step": dt * 1e3 / steps, "cell_steps_per_s": batch * h * w * steps / dt,
                "finite": bool(torch.isfinite(out).all())}
         print(json.dumps(res), flush=True)
