@@ -602,16 +602,27 @@ __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x
   gelu_erf8(g_prev[2], g_prev[3]);
 #pragma unroll
   for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
-  for (int t = 1; t < ntile; ++t) {
-    const int tn = (t + 1 < ntile) ? t + 1 : t;
-    u32x4 wa[3];
+  // LDS operands are fetched ONE TILE AHEAD of the MFMAs / FMAs that consume them (the matrix instructions at the top
+  // of an iteration would otherwise wait out the LDS latency every tile)
+  u32x4 wa[3], wa_n[3];
+  f32x4 w2v[CO], w2v_n[CO], bb, bb_n;
+  {
+    const int tn = ntile > 2 ? 2 : ntile - 1;
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp) wa[pp] = s_w1[(tn * 3 + pp) * 64 + lane];
-    f32x4 w2v[CO];
 #pragma unroll
-    for (int co = 0; co < CO; ++co)
-      w2v[co] = *reinterpret_cast<const f32x4*>(s_w2 + ((t - 1) * CO + co) * 16 + 4 * g);
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * tn + 4 * g);
+    for (int co = 0; co < CO; ++co) w2v[co] = *reinterpret_cast<const f32x4*>(s_w2 + co * 16 + 4 * g);
+    bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * tn + 4 * g);
+  }
+  for (int t = 1; t < ntile; ++t) {
+    {   // operands of iteration t + 1: tile min(t + 2, ntile - 1) for layer 1, tile t for layer 2
+      const int tn2 = (t + 2 < ntile) ? t + 2 : ntile - 1;
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) wa_n[pp] = s_w1[(tn2 * 3 + pp) * 64 + lane];
+#pragma unroll
+      for (int co = 0; co < CO; ++co) w2v_n[co] = *reinterpret_cast<const f32x4*>(s_w2 + (t * CO + co) * 16 + 4 * g);
+      bb_n = *reinterpret_cast<const f32x4*>(s_b1 + 16 * tn2 + 4 * g);
+    }
     // two slots: the bf16 MFMAs of tile tn for two pixel chains (matrix pipe), then GELU of two
     // accumulator fragments of tile t and the layer-2 FMAs of tile t-1 (fp32 lanes)
 #pragma unroll
@@ -634,6 +645,11 @@ __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x
       g_prev[q] = g_new[q];
       a_cur[q] = a_nxt[q];
     }
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) wa[pp] = wa_n[pp];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) w2v[co] = w2v_n[co];
+    bb = bb_n;
   }
   {
     const int t = ntile - 1;
