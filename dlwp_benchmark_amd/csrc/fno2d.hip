@@ -1097,6 +1097,15 @@ __global__ __launch_bounds__(1024) void fno_modes_kernel(const ModesParams p) {
 // an XCD (workgroup i runs on XCD i % 8, so a sample's workgroups are i, i+8, ...).
 // ---------------------------------------------------------------------------------------------
 constexpr int kTrunkMaxLayers = 8;
+// W-direction DFTs of the fused kernel's row phase on the bf16 matrix pipe (bf16x6) instead of fp32 MFMA.  Built,
+// parity-green (rel-L2 3.7e-7 after 20 steps) and measured: NO gain (inverse 0.77 vs 0.88 us, forward 0.72 vs 0.76 us for
+// the first wave of a SIMD, launch 1.891 vs 1.887 ms) -- K is only 16 / 64 deep, so the extra LDS reads, the operand
+// splits and the six dependent MFMAs per accumulator cost what the freed fp32 lanes give back.  Default: the fp32 form
+// (exact fp32 FMA chains); -DDLWP_TRUNK_DFT_BF16=1 rebuilds the bf16x6 form.
+#ifndef DLWP_TRUNK_DFT_BF16
+#define DLWP_TRUNK_DFT_BF16 0
+#endif
+constexpr bool kDftBf16 = DLWP_TRUNK_DFT_BF16 != 0;
 constexpr int kSyStride = 528;   // floats per Y row in LDS: 16 k' x 32 c + 16 (bank spread for the P1 B reads)
 
 struct TrunkParams {
@@ -1105,6 +1114,8 @@ struct TrunkParams {
   const float* ybuf;   // [B][H][16][32] W-direction DFT of x (emitted by the lifting kernel)
   const float* t;      // T[16][64]
   const float* tt;     // TT[64][16]
+  const u32x4* tb;     // [4 q][3][64]   bf16x3 B operands of the inverse W-DFT
+  const u32x4* ttb;    // [2 kb][3][64]  bf16x3 B operands of the forward W-DFT
   const float2* ef;    // [M1][H]
   const float2* ei;    // [M1][H]
   const float* ck;     // [M2]
@@ -1272,6 +1283,34 @@ __device__ __forceinline__ void rollout_step_io(const TrunkParams& p, int t, lon
 
 // STEP: the whole backbone step in this launch -- the lifting MLP produces the resident activation and its first Y row,
 // the projection MLP (+ residual) consumes the last one; their staged weights time-share the transpose tiles' LDS.
+// Forward W-direction DFT of the wave's 32 x 64 tile in its transpose area, bf16x6: A = 8 consecutive pixels of a channel
+// row (two 16-byte LDS reads, split into three bf16 parts), B = the pre-split twiddles.
+__device__ __forceinline__ void fwd_dft_bf16x6(const float* s_tr, const u32x4* s_ttb, int lane, f32x4 (&yacc)[2]) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    u32x4 tb[3];
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) tb[pp] = s_ttb[(kb * 3 + pp) * 64 + lane];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float* src = s_tr + (16 * ct + j) * kTrStride + 32 * kb + 8 * g;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+      u32x4 xa[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned hh, mm, ll;
+        const float v0 = i < 2 ? a0[2 * i] : a1[2 * i - 4], v1 = i < 2 ? a0[2 * i + 1] : a1[2 * i - 3];
+        split3_pair(v0, v1, hh, mm, ll);
+        xa[0][i] = hh;
+        xa[1][i] = mm;
+        xa[2][i] = ll;
+      }
+      yacc[ct] = mfma_bf16x6(xa, tb, yacc[ct]);
+    }
+  }
+}
+
 template <int ROWS, int G, bool LL, bool STEP = false>
 __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkParams p) {
   extern __shared__ __align__(16) float smem[];
@@ -1288,6 +1327,8 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   int* s_fast = s_fail + 1;                               // LL: the sample's group shares one XCD (found in layer 0)
   float2* s_ef = reinterpret_cast<float2*>(s_fail + 4);   // [16][ROWS]  EF rows of this workgroup's grid rows (0 beyond M1)
   float2* s_ei = s_ef + 16 * ROWS;                        // [16][ROWS]  EI likewise
+  u32x4* s_tb = reinterpret_cast<u32x4*>(s_ei + 16 * ROWS);   // [4][3][64]  inverse W-DFT B operands (bf16x3)
+  u32x4* s_ttb = s_tb + 4 * 3 * 64;                           // [2][3][64]  forward W-DFT B operands (bf16x3)
   const int H = p.H, M1 = p.M1, M2 = p.M2, NM = M1 * M2;
   int sample, member;
   {
@@ -1325,6 +1366,8 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     s_ef[i] = r < M1 ? p.ef[r * H + member * ROWS + hl] : float2{0.f, 0.f};
     s_ei[i] = r < M1 ? p.ei[r * H + member * ROWS + hl] : float2{0.f, 0.f};
   }
+  for (int i = tid; i < 4 * 3 * 64; i += NT) s_tb[i] = p.tb[i];
+  for (int i = tid; i < 2 * 3 * 64; i += NT) s_ttb[i] = p.ttb[i];
   lds_barrier();   // the tables above are read by every wave right away
 
   // STEP: the steps of this launch (one, or a whole rollout range without the host in the loop: a row's next input
@@ -1381,11 +1424,15 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         *reinterpret_cast<f32x4*>(s_tr + (16 * ot + 4 * g + r) * kTrStride + 4 * j) = vv[ot][r];
     wave_lds_fence();
     f32x4 yacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (kDftBf16) {
+      fwd_dft_bf16x6(s_tr, s_ttb, lane, yacc);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+      for (int s = 0; s < 16; ++s)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-        yacc[ct] = mfma16x16x4(s_tr[(16 * ct + j) * kTrStride + 4 * s + g], s_tt[(4 * s + g) * KP + j], yacc[ct]);
+        for (int ct = 0; ct < 2; ++ct)
+          yacc[ct] = mfma16x16x4(s_tr[(16 * ct + j) * kTrStride + 4 * s + g], s_tt[(4 * s + g) * KP + j], yacc[ct]);
+    }
     wave_lds_fence();
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -1678,25 +1725,59 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4)
-          if (2 * g + (r4 >> 1) < ROWS) s_z[(2 * g + (r4 >> 1)) * (KP * C) + (2 * ky + (r4 & 1)) * C + 16 * nt + j] = d[r4] * ckw;
+          if (2 * g + (r4 >> 1) < ROWS) {
+            const int kq = 2 * ky + (r4 & 1), o = 16 * nt + j;   // bf16 form keeps Z as [row][o][k'], fp32 form as [row][k'][o]
+            s_z[(2 * g + (r4 >> 1)) * (KP * C) + (kDftBf16 ? o * KP + kq : kq * C + o)] = d[r4] * ckw;
+          }
       }
       wave_lds_fence();   // the transpose tile is reused for the next ky
     }
     lds_barrier();
     DLWP_STAMP();
     // ---- the row itself
-    float z[KP / 4][2];
+    if constexpr (kDftBf16) {
+      // inverse W-DFT, bf16x6: A = Z[o = 16 ot + j][k' = 8g .. 8g+7] (lane groups 2, 3 carry zeros: K = 16 of 32)
+      u32x4 za[2][3];
 #pragma unroll
-    for (int s = 0; s < KP / 4; ++s)
+      for (int ot = 0; ot < 2; ++ot) {
+        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;
+        if (g < 2) {
+          const float* src = s_z + wave * (KP * C) + (16 * ot + j) * KP + 8 * g;
+          z0 = *reinterpret_cast<const f32x4*>(src);
+          z1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot) z[s][ot] = s_z[wave * (KP * C) + (4 * s + g) * C + 16 * ot + j];
+        for (int i = 0; i < 4; ++i) {
+          unsigned hh, mm, ll;
+          const float v0 = i < 2 ? z0[2 * i] : z1[2 * i - 4], v1 = i < 2 ? z0[2 * i + 1] : z1[2 * i - 3];
+          split3_pair(v0, v1, hh, mm, ll);
+          za[ot][0][i] = hh;
+          za[ot][1][i] = mm;
+          za[ot][2][i] = ll;
+        }
+      }
 #pragma unroll
-    for (int s = 0; s < KP / 4; ++s) {
-      const f32x4 tw = *reinterpret_cast<const f32x4*>(s_t + (4 * s + g) * W + 4 * j);
+      for (int q = 0; q < 4; ++q) {
+        u32x4 tb[3];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int pp = 0; pp < 3; ++pp) tb[pp] = s_tb[(q * 3 + pp) * 64 + lane];
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma16x16x4(z[s][ot], tw[q], acc[ot][q]);
+        for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma_bf16x6(za[ot], tb, acc[ot][q]);
+      }
+    } else {
+      float z[KP / 4][2];
+#pragma unroll
+      for (int s = 0; s < KP / 4; ++s)
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) z[s][ot] = s_z[wave * (KP * C) + (4 * s + g) * C + 16 * ot + j];
+#pragma unroll
+      for (int s = 0; s < KP / 4; ++s) {
+        const f32x4 tw = *reinterpret_cast<const f32x4*>(s_t + (4 * s + g) * W + 4 * j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma16x16x4(z[s][ot], tw[q], acc[ot][q]);
+      }
     }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -1719,11 +1800,15 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
       wave_lds_fence();
       DLWP_STAMP();
       f32x4 yacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      if constexpr (kDftBf16) {
+        fwd_dft_bf16x6(s_tr, s_ttb, lane, yacc);
+      } else {
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
+        for (int s = 0; s < 16; ++s)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          yacc[ct] = mfma16x16x4(s_tr[(16 * ct + j) * kTrStride + 4 * s + g], s_tt[(4 * s + g) * KP + j], yacc[ct]);
+          for (int ct = 0; ct < 2; ++ct)
+            yacc[ct] = mfma16x16x4(s_tr[(16 * ct + j) * kTrStride + 4 * s + g], s_tt[(4 * s + g) * KP + j], yacc[ct]);
+      }
       wave_lds_fence();
       DLWP_STAMP();
 #pragma unroll
@@ -1829,6 +1914,7 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
   int H = 0, W = 0, M1 = 0, M2 = 0, KP = 0;
   float fwd_scale = 1.f;
   DevBuf t, tt, ef, ei, ck;
+  DevBuf tb, ttb;   // bf16x3 B operands of the W-direction DFTs for the fused kernel (W == 64, KP == 16 only)
 
   int32_t build(int H_, int W_, int M1_, int M2_, const int32_t* rows_in, const int32_t* rows_out,
                 float fwd, float inv, hipStream_t s) {
@@ -1861,6 +1947,39 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
     for (int ky = 0; ky < M2; ++ky) {
       const bool self_conj = (ky == 0) || (W % 2 == 0 && ky == W / 2);
       hck[ky] = (self_conj ? 1.f : 2.f) * inv;
+    }
+    if (W == 64 && KP == 16) {
+      // inverse: B[k = k' = 8g + jj][col j -> pixel 4j + q]  -> [q][part][lane][dword]   (lanes g >= 2 supply zeros)
+      // forward: B[k = pixel 32kb + 8g + jj][col j -> k' = j] -> [kb][part][lane][dword]
+      std::vector<uint32_t> htb((size_t)4 * 3 * 64 * 4, 0u), httb((size_t)2 * 3 * 64 * 4, 0u);
+      for (int l = 0; l < 64; ++l) {
+        const int jj0 = l & 15, gg = l >> 4;
+        for (int d = 0; d < 4; ++d) {
+          for (int q = 0; q < 4; ++q) {
+            uint16_t hh[2], mm[2], ll[2];
+            for (int e = 0; e < 2; ++e) {
+              const int kp = 8 * gg + 2 * d + e;
+              split3_host(kp < KP ? ht[(size_t)kp * W + 4 * jj0 + q] : 0.f, hh[e], mm[e], ll[e]);
+            }
+            htb[(((size_t)q * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+            htb[(((size_t)q * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16);
+            htb[(((size_t)q * 3 + 2) * 64 + l) * 4 + d] = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
+          }
+          for (int kb = 0; kb < 2; ++kb) {
+            uint16_t hh[2], mm[2], ll[2];
+            for (int e = 0; e < 2; ++e) {
+              const int w = 32 * kb + 8 * gg + 2 * d + e;
+              split3_host(htt[(size_t)w * KP + jj0], hh[e], mm[e], ll[e]);
+            }
+            httb[(((size_t)kb * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+            httb[(((size_t)kb * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16);
+            httb[(((size_t)kb * 3 + 2) * 64 + l) * 4 + d] = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
+          }
+        }
+      }
+      DLWP_HIP_CHECK(tb.upload(htb.data(), htb.size() * 4, s));
+      DLWP_HIP_CHECK(ttb.upload(httb.data(), httb.size() * 4, s));
+      DLWP_HIP_CHECK(hipStreamSynchronize(s));
     }
     DLWP_HIP_CHECK(t.upload(ht.data(), ht.size() * 4, s));
     DLWP_HIP_CHECK(tt.upload(htt.data(), htt.size() * 4, s));
@@ -2282,7 +2401,8 @@ bool trunk_enabled() {
   return on;
 }
 constexpr size_t trunk_lds(int rows) {
-  return ((size_t)rows * kC * kTrStride + rows * kSyStride + rows * 16 * kC + rows * 128 + 2 * 16 * 64 + 4 + 2 * 2 * 16 * rows) *
+  return ((size_t)rows * kC * kTrStride + rows * kSyStride + rows * 16 * kC + rows * 128 + 2 * 16 * 64 + 4 + 2 * 2 * 16 * rows +
+          6 * 3 * 64 * 4) *
          sizeof(float);
 }
 // rows (= waves) per workgroup.  8 = one workgroup per CU (default).  4 puts two workgroups on a CU (2 x 61 KB of
@@ -2411,6 +2531,7 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
     TrunkParams tp = {};
     tp.x = hin; tp.y = hout; tp.ybuf = ws.ybuf;
     tp.t = p->sc.t.as<float>(); tp.tt = p->sc.tt.as<float>();
+    tp.tb = p->sc.tb.as<u32x4>(); tp.ttb = p->sc.ttb.as<u32x4>();
     tp.ef = p->sc.ef.as<float2>(); tp.ei = p->sc.ei.as<float2>(); tp.ck = p->sc.ck.as<float>();
     for (int l = 0; l < kTrunkMaxLayers; ++l) {
       const int ll = l < p->L ? l : 0;
