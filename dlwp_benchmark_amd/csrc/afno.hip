@@ -93,6 +93,107 @@ __global__ __launch_bounds__(256) void afno_mix_kernel(const Params p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// MFMA form for block size 16 (FourCastNet: embed 64 / 4 blocks, embed 768 / ... -> bs 16 is the BASELINE case).
+// A block's complex 16 -> 16 -> 16 MLP is a real 32 -> 32 -> 32 one with W_real = [[Wr, Wi], [-Wi, Wr]]; it is
+// evaluated TRANSPOSED, D[n][point] = sum_k W_real^T[n][k] x^T[k][point], on v_mfma_f32_16x16x4_f32:
+//   * one wave-iteration = 16 consecutive kept points of one spectrum row (the MFMA's columns, lane & 15);
+//   * B operand of layer 1 = the spectrum itself: lane (j, g) loads float2 x[point j][channel 4s + g], s = 0..3
+//     (coalesced 8-byte loads) and feeds .x in k-step s, .y in k-step s + 4  (k = ri * 16 + channel);
+//   * the accumulator of layer 1 (rows n = 16 nt + 4 g + r of point j) IS the B operand of layer 2 -- k-step (nt, r)
+//     supplies hidden index 16 nt + 4 g + r, the weights of layer 2 are gathered in that k order;
+//   * layer 2's accumulator holds re (tile 0) and im (tile 1) of output channel 4 g + r of point j in the same lane:
+//     one coalesced float2 store per channel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
+  constexpr int BS = 16;
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const long long plane = (long long)p.H * p.Wf;
+  const int kt = (p.km + 15) / 16;                       // 16-point tiles per spectrum row
+  const int nrows = p.row_hi - p.row_lo;
+  const long long ntiles = (long long)p.B * nrows * kt;
+  // wave w of the workgroup owns channel block w (w + 4, ...): its weights are gathered into registers ONCE and
+  // reused for every 16-point tile the workgroup visits
+  const int wave = threadIdx.x >> 6;
+  for (int blk = wave; blk < p.nb; blk += 4) {
+    // ---- operands: weights of this block in MFMA A layout (row n = lane & 15 of tile nt, k = 4 s + g)
+    float a1[2][8], a2[2][8];
+    const float* w1r = p.w1 + (long long)blk * BS * BS;
+    const float* w1i = w1r + (long long)p.nb * BS * BS;
+    const float* w2r = p.w2 + (long long)blk * BS * BS;
+    const float* w2i = w2r + (long long)p.nb * BS * BS;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)        // output tile: 0 = real parts, 1 = imaginary parts; output channel o = j
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        {   // layer 1: k = ri * 16 + ch, ri = s >> 2, ch = 4 (s & 3) + g
+          const int ri = s >> 2, ch = 4 * (s & 3) + g;
+          const float wr = w1r[ch * BS + j], wi = w1i[ch * BS + j];
+          a1[nt][s] = nt == 0 ? (ri == 0 ? wr : -wi) : (ri == 0 ? wi : wr);
+        }
+        {   // layer 2: k-step s = (nt1, r1) supplies hidden index (ro1 = nt1, o1 = 4 g + r1)
+          const int ri = s >> 2, ch = 4 * g + (s & 3);
+          const float wr = w2r[ch * BS + j], wi = w2i[ch * BS + j];
+          a2[nt][s] = nt == 0 ? (ri == 0 ? wr : -wi) : (ri == 0 ? wi : wr);
+        }
+      }
+    f32x4 bias1[2], bias2[2];   // bias of row n = 16 nt + 4 g + r: b[ro = nt][blk][o = 4 g + r]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float* bb1 = p.b1 + (long long)nt * p.nb * BS + blk * BS + 4 * g;
+      const float* bb2 = p.b2 + (long long)nt * p.nb * BS + blk * BS + 4 * g;
+      bias1[nt] = f32x4{bb1[0], bb1[1], bb1[2], bb1[3]};
+      bias2[nt] = f32x4{bb2[0], bb2[1], bb2[2], bb2[3]};
+    }
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const int tile = (int)(t % kt);
+      const int h = p.row_lo + (int)((t / kt) % nrows);
+      const int b = (int)(t / ((long long)kt * nrows));
+      const int col = tile * 16 + j;
+      const bool live = col < p.km;
+      const long long base = (long long)b * p.C * plane + (long long)h * p.Wf + (live ? col : 0);
+      // ---- layer 1
+      float2 xin[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xin[s] = live ? p.x[base + (long long)(blk * BS + 4 * s + g) * plane] : float2{0.f, 0.f};
+      f32x4 d1[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        d1[nt] = bias1[nt];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) d1[nt] = mfma16x16x4(a1[nt][s], s < 4 ? xin[s].x : xin[s - 4].y, d1[nt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1[nt][r] = fmaxf(d1[nt][r], 0.f);
+      }
+      // ---- layer 2 (B operand = layer-1 accumulator as it stands)
+      f32x4 d2[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        d2[nt] = bias2[nt];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) d2[nt] = mfma16x16x4(a2[nt][s], d1[s >> 2][s & 3], d2[nt]);
+      }
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          p.y[base + (long long)(blk * BS + 4 * g + r) * plane] =
+              float2{softshrink(d2[0][r], p.lambd), softshrink(d2[1][r], p.lambd)};
+      }
+    }
+  }
+}
+
+// zeros outside the kept rows / columns (the MFMA kernel writes only kept points)
+__global__ __launch_bounds__(256) void afno_zero_fill_kernel(const Params p) {
+  const long long total = (long long)p.B * p.C * p.H * p.Wf;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % p.Wf);
+    const int h = (int)((i / p.Wf) % p.H);
+    if (w >= p.km || h < p.row_lo || h >= p.row_hi) p.y[i] = float2{0.f, 0.f};
+  }
+}
+
 }  // namespace afno
 }  // namespace dlwp
 
@@ -125,7 +226,15 @@ extern "C" int32_t dlwp_afno2d_mix_f32(const float* xf, float* yf, const float* 
   switch (bs) {
     case 4: hipLaunchKernelGGL(afno::afno_mix_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
     case 8: hipLaunchKernelGGL(afno::afno_mix_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
-    case 16: hipLaunchKernelGGL(afno::afno_mix_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 16: {
+      // MFMA form: kept points on the matrix lanes, zeros elsewhere by a plain fill
+      hipLaunchKernelGGL(afno::afno_zero_fill_kernel, dim3(256 * 8), dim3(256), 0, s, p);
+      const long long tiles = (long long)batch * (p.row_hi - p.row_lo) * ((p.km + 15) / 16);
+      long long wg = tiles;
+      if (wg > 256 * 8) wg = 256 * 8;
+      hipLaunchKernelGGL(afno::afno_mix_mfma16_kernel, dim3((unsigned)(wg > 0 ? wg : 1)), dim3(256), 0, s, p);
+      break;
+    }
     case 32: hipLaunchKernelGGL(afno::afno_mix_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
     default: return fail(DLWP_ERR_UNSUPPORTED, "AFNO block size %d not supported (4, 8, 16, 32)", bs);
   }
