@@ -196,8 +196,9 @@ __global__ __launch_bounds__(256) void ln_nhwc_to_nchw_kernel(const float* __res
 template <int NV>
 __global__ __launch_bounds__(256) void afno_merge_kernel(const float* __restrict__ f, const float* __restrict__ l,
                                                         const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ s_out,
-                                                        float* __restrict__ n_out, int B, long long T, int C, float eps) {
+                                                        const float* __restrict__ beta, const float* __restrict__ sum_bias,
+                                                        float* __restrict__ s_out, float* __restrict__ n_out, int B,
+                                                        long long T, int C, float eps) {
   extern __shared__ __align__(16) float smem[];   // [TT][C + 4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 15, tq = lane >> 4;
@@ -211,6 +212,12 @@ __global__ __launch_bounds__(256) void afno_merge_kernel(const float* __restrict
     const int iv = sub + 16 * v;
     gm[v] = iv < nvec ? *reinterpret_cast<const f32x4*>(gamma + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
     bt[v] = iv < nvec ? *reinterpret_cast<const f32x4*>(beta + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 sb[NV];   // optional per-channel constant added to the STORED sum only (not to the LayerNorm input)
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int iv = sub + 16 * v;
+    sb[v] = (sum_bias && iv < nvec) ? *reinterpret_cast<const f32x4*>(sum_bias + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int b = (int)(tile / tiles_per_b);
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256) void afno_merge_kernel(const float* __restrict
         if (live && iv < nvec) {
           const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((long long)b * T + tok) * C + 4 * iv);
           sv[v] = *reinterpret_cast<const f32x4*>(smem + tl * ld + 4 * iv) + xv;
-          *reinterpret_cast<f32x4*>(s_out + ((long long)b * T + tok) * C + 4 * iv) = sv[v];
+          *reinterpret_cast<f32x4*>(s_out + ((long long)b * T + tok) * C + 4 * iv) = sv[v] + sb[v];
         } else {
           sv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -302,8 +309,8 @@ extern "C" int32_t dlwp_layernorm_nhwc_to_nchw_f32(const float* x, const float* 
 }
 
 extern "C" int32_t dlwp_afno_merge_f32(const float* f_nchw, const float* l_nchw, const float* x_nhwc, const float* gamma,
-                                       const float* beta, float* sum_nhwc, float* norm_nhwc, int32_t batch,
-                                       int64_t tokens, int32_t channels, float eps, void* stream) {
+                                       const float* beta, const float* sum_bias, float* sum_nhwc, float* norm_nhwc,
+                                       int32_t batch, int64_t tokens, int32_t channels, float eps, void* stream) {
   DLWP_REQUIRE(f_nchw && l_nchw && x_nhwc && gamma && beta && sum_nhwc && norm_nhwc, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0 && tokens > 0 && channels > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
   DLWP_REQUIRE(channels % 4 == 0 && channels <= 256, DLWP_ERR_UNSUPPORTED, "channels %d: multiple of 4, <= 256", channels);
@@ -318,7 +325,7 @@ extern "C" int32_t dlwp_afno_merge_f32(const float* f_nchw, const float* l_nchw,
       DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(norm::afno_merge_kernel<NV_>),                \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
     hipLaunchKernelGGL((norm::afno_merge_kernel<NV_>), dim3(grid), dim3(256), lds, s, f_nchw, l_nchw, x_nhwc, gamma,  \
-                       beta, sum_nhwc, norm_nhwc, batch, (long long)tokens, channels, eps);                          \
+                       beta, sum_bias, sum_nhwc, norm_nhwc, batch, (long long)tokens, channels, eps);                          \
   } while (0)
   switch (nv) { case 1: DLWP_M(1); break; case 2: DLWP_M(2); break; case 3: DLWP_M(3); break; default: DLWP_M(4); break; }
 #undef DLWP_M

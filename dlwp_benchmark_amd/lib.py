@@ -78,7 +78,7 @@ SIGNATURES = {
     "dlwp_layernorm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_float, c_void_p]),
     "dlwp_layernorm_nhwc_to_nchw_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64, c_int32,
                                                   c_float, c_void_p]),
-    "dlwp_afno_merge_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+    "dlwp_afno_merge_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                       ctypes.c_int64, c_int32, c_float, c_void_p]),
     "dlwp_weighted_error_sums_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                c_int32, c_int32, c_int32, c_void_p]),

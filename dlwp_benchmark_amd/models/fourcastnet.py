@@ -67,8 +67,13 @@ class _Block(nn.Module):
         layout change is fused with `+ bias`, the first skip and LayerNorm2 (dlwp_afno_merge_f32)."""
         l_cf = ops.layernorm_nhwc_to_nchw(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         f_cf = self.filter.filter_cf(l_cf)
-        s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return self.mlp(n) + s
+        # second skip (:192) folded into the fc2 GEMM: the merge kernel stores sum + fc2.bias, addmm adds it (beta = 1)
+        m = self.mlp
+        s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, sum_bias=m.fc2.bias)
+        hid = torch.nn.functional.gelu(torch.nn.functional.linear(n, m.fc1.weight, m.fc1.bias))
+        c = x.shape[-1]
+        s.view(-1, c).addmm_(hid.view(-1, hid.shape[-1]), m.fc2.weight.t())   # in place: no copy of the addend
+        return s
 
 
 class _PatchEmbed(nn.Module):

@@ -201,8 +201,9 @@ def layernorm_nhwc_to_nchw(x: torch.Tensor, weight, bias, eps: float) -> torch.T
     return y
 
 
-def afno_merge(f_nchw: torch.Tensor, l_nchw: torch.Tensor, x_nhwc: torch.Tensor, weight, bias, eps: float):
-    """(f + l) transposed to token-major + x -> (sum, LayerNorm(sum)), both [B, H, W, C]."""
+def afno_merge(f_nchw: torch.Tensor, l_nchw: torch.Tensor, x_nhwc: torch.Tensor, weight, bias, eps: float,
+               sum_bias: Optional[torch.Tensor] = None):
+    """(f + l) transposed to token-major + x -> (sum [+ sum_bias], LayerNorm(sum)), both [B, H, W, C]."""
     for t, n in ((f_nchw, "f"), (l_nchw, "l"), (x_nhwc, "x")):
         _lib.require_cuda_tensor(t, n)
     f_nchw, l_nchw, x_nhwc = f_nchw.contiguous(), l_nchw.contiguous(), x_nhwc.contiguous()
@@ -212,8 +213,10 @@ def afno_merge(f_nchw: torch.Tensor, l_nchw: torch.Tensor, x_nhwc: torch.Tensor,
     lib = _lib.load()
     with torch.cuda.device(x_nhwc.device):
         _lib.check(lib.dlwp_afno_merge_f32(f_nchw.data_ptr(), l_nchw.data_ptr(), x_nhwc.data_ptr(),
-                                           weight.contiguous().data_ptr(), bias.contiguous().data_ptr(), s.data_ptr(),
-                                           n.data_ptr(), b, h * w, c, float(eps), _lib.stream_ptr()), "dlwp_afno_merge_f32")
+                                           weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                                           sum_bias.contiguous().data_ptr() if sum_bias is not None else None,
+                                           s.data_ptr(), n.data_ptr(), b, h * w, c, float(eps), _lib.stream_ptr()),
+                   "dlwp_afno_merge_f32")
     return s, n
 
 

@@ -266,13 +266,14 @@ int32_t dlwp_layernorm_f32(const float* x_dev, const float* gamma_dev, const flo
  *   dlwp_layernorm_nhwc_to_nchw_f32: y = LayerNorm1(x), written channel-major (:182 norm1 + the transpose
  *       torch.fft.rfft2(dim=(1,2)) would otherwise do with a strided copy)
  *   dlwp_afno_merge_f32: sum = f + l + x  (irfft2 output + AFNO2D "+ bias" :127 + first skip :187),
- *       norm = LayerNorm2(sum) (:191); both token-major. */
+ *       norm = LayerNorm2(sum) (:191); both token-major.  sum_bias_dev [C] or NULL is added to the STORED sum only:
+ *       the host passes mlp.fc2.bias so that `mlp(norm) + sum` (:192) becomes one GEMM with beta = 1. */
 int32_t dlwp_layernorm_nhwc_to_nchw_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev,
                                         float* y_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
                                         void* stream);
 int32_t dlwp_afno_merge_f32(const float* f_nchw_dev, const float* l_nchw_dev, const float* x_nhwc_dev,
-                            const float* gamma_dev, const float* beta_dev, float* sum_nhwc_dev,
-                            float* norm_nhwc_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
+                            const float* gamma_dev, const float* beta_dev, const float* sum_bias_dev,
+                            float* sum_nhwc_dev, float* norm_nhwc_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
                             void* stream);
 
 /* On-device evaluation sums (reference scripts/evaluate.py:786-821 `compute_metrics` + the
