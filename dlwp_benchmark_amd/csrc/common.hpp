@@ -161,6 +161,45 @@ __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
   v = f32x4{r4, r5, r6, r7};
 }
 
+// The same GELU on eight plain v_fma_f32 chains.  For kernels whose SIMD also issues bf16 MFMAs (its own or the
+// partner wave's): an MFMA and a VALU instruction share the SIMD's issue port, and beside MFMAs a packed-fp32
+// instruction costs much more than the two plain ones it replaces (MI355X_MICROARCH.md, constants table: one
+// v_pk_fma_f32 = +22 cycles over two v_fma_f32) -- the token MLP went 516 -> see token_mlp.hip with this form.
+__device__ __forceinline__ void gelu_erf8_fma(f32x4& u, f32x4& v) {
+  const float x0 = u[0], x1 = u[1], x2 = u[2], x3 = u[3], x4 = v[0], x5 = v[1], x6 = v[2], x7 = v[3];
+  const float umax = DLWP_GELU_UMAX;
+  // first reads in plain C (MFMA -> VALU hazard, see gelu_erf8)
+  const float t0 = fminf(fabsf(x0), umax), t1 = fminf(fabsf(x1), umax), t2 = fminf(fabsf(x2), umax),
+              t3 = fminf(fabsf(x3), umax), t4 = fminf(fabsf(x4), umax), t5 = fminf(fabsf(x5), umax),
+              t6 = fminf(fabsf(x6), umax), t7 = fminf(fabsf(x7), umax);
+  float p0 = DLWP_GELU_Q8, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
+#define DLWP_FSTEP1(p, t, cf) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(t), "s"(cf));
+#define DLWP_FSTEP8(cf)                                                                        \
+  {                                                                                            \
+    const float cc = cf;                                                                       \
+    DLWP_FSTEP1(p0, t0, cc) DLWP_FSTEP1(p1, t1, cc) DLWP_FSTEP1(p2, t2, cc) DLWP_FSTEP1(p3, t3, cc) \
+    DLWP_FSTEP1(p4, t4, cc) DLWP_FSTEP1(p5, t5, cc) DLWP_FSTEP1(p6, t6, cc) DLWP_FSTEP1(p7, t7, cc) \
+  }
+  DLWP_GELU_COEFFS(DLWP_FSTEP8)
+  DLWP_FSTEP8(-1.0f)   // exponent u Q(u) - 1
+#undef DLWP_FSTEP8
+#undef DLWP_FSTEP1
+  float m0, m1, m2, m3, m4, m5, m6, m7, e0, e1, e2, e3, e4, e5, e6, e7;
+#define DLWP_X(m, x) asm volatile("v_max_f32_e32 %0, 0, %1" : "=v"(m) : "v"(x));
+#define DLWP_E(e, a) asm volatile("v_exp_f32_e32 %0, %1" : "=v"(e) : "v"(a));
+  DLWP_E(e0, p0) DLWP_X(m0, x0) DLWP_E(e1, p1) DLWP_X(m1, x1) DLWP_E(e2, p2) DLWP_X(m2, x2) DLWP_E(e3, p3) DLWP_X(m3, x3)
+  DLWP_E(e4, p4) DLWP_X(m4, x4) DLWP_E(e5, p5) DLWP_X(m5, x5) DLWP_E(e6, p6) DLWP_X(m6, x6) DLWP_E(e7, p7) DLWP_X(m7, x7)
+#undef DLWP_E
+#undef DLWP_X
+  float r0, r1, r2, r3, r4, r5, r6, r7;
+#define DLWP_F(r, x, h, m) asm volatile("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(r) : "v"(x), "v"(h), "v"(m));
+  DLWP_F(r0, x0, e0, m0) DLWP_F(r1, x1, e1, m1) DLWP_F(r2, x2, e2, m2) DLWP_F(r3, x3, e3, m3)
+  DLWP_F(r4, x4, e4, m4) DLWP_F(r5, x5, e5, m5) DLWP_F(r6, x6, e6, m6) DLWP_F(r7, x7, e7, m7)
+#undef DLWP_F
+  u = f32x4{r0, r1, r2, r3};
+  v = f32x4{r4, r5, r6, r7};
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 GEMM on the bf16 matrix pipe ("bf16x6")
 //   x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (exact to 2^-24 |x|)

@@ -1,0 +1,334 @@
+// Token MLP of the AFNO block (reference fourcastnet.py:41-57 `Mlp`, called at :191-192):
+//   out[t][:] = resid[t][:] + b2 + W2 * gelu(W1 * n[t][:] + b1),   n / resid / out token-major [T][C], C = 64.
+// torch runs this as GEMM -> GELU -> GEMM with the [T][4C] hidden activation making four trips through HBM
+// (1 GB each at 128x256x32 tokens).  Here one wave owns 32 tokens at a time and the hidden activation never
+// leaves its registers: both layers run on the bf16 matrix pipe as bf16x6 (every fp32 operand split exactly into
+// three bf16 parts, six cross products accumulated in fp32 -- fp32-GEMM accuracy, see common.hpp), the GELU
+// output of layer 1 IS the B operand of layer 2 in accumulator order (hidden tiles are taken in pairs so that
+// the 8 registers a lane holds are the 8 k-slots it supplies, as in the FNO lifting kernel).
+//
+// Operand layout (v_mfma_f32_16x16x32_bf16: lane (j = l & 15, g = l >> 4) supplies k-slots 8g..8g+7 of row/column j
+// and receives rows 4g..4g+3 of column j):
+//   layer 1: A = W1 tile t (hidden 16t + j), k-step ks: channel 32 ks + 8 g + e;  B = token (q, j) = base + 16 q + j
+//   layer 2: A = W2 tile ot (out channel 16 ot + j), pair u: k-slot (g, e) = hidden 16 (2u + e/4) + 4 g + e%4
+// Weights: the h and m parts of both layers live in LDS (C = 64, hid = 256: 128 KB), the l parts (used by one of the
+// six products) are read from global memory -- 192 KB of A operands do not fit the CU's 160 KB.
+#include "common.hpp"
+
+namespace dlwp {
+namespace tmlp {
+
+struct Params {
+  const float* n;
+  const float* resid;   // nullable
+  const float* b2;      // nullable
+  float* out;
+  const u32x4* w1hm;    // [hid/16][KS][2][64]
+  const u32x4* w1l;     // [hid/16][KS][64]
+  const u32x4* w2hm;    // [hid/32][2][OT][64]
+  const u32x4* w2l;     // [hid/32][OT][64]
+  const float* b1;      // [hid]
+  long long T;
+  int hid;
+  unsigned long long* trace;   // diagnostics (DLWP_TMLP_TRACE): [wave of workgroup 0][256] s_memtime stamps, or null
+};
+
+// packed-buffer layout (u32x4 units): w1hm | w2hm | w1l | w2l
+__host__ __device__ inline size_t n_w1hm(int hid, int KS) { return (size_t)(hid / 16) * KS * 2 * 64; }
+__host__ __device__ inline size_t n_w2hm(int hid, int OT) { return (size_t)(hid / 32) * 2 * OT * 64; }
+__host__ __device__ inline size_t n_w1l(int hid, int KS) { return (size_t)(hid / 16) * KS * 64; }
+__host__ __device__ inline size_t n_w2l(int hid, int OT) { return (size_t)(hid / 32) * OT * 64; }
+
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                   unsigned* __restrict__ dst, int C, int hid) {
+  const int KS = C / 32, OT = C / 16;
+  unsigned* w1hm = dst;
+  unsigned* w2hm = w1hm + n_w1hm(hid, KS) * 4;
+  unsigned* w1l = w2hm + n_w2hm(hid, OT) * 4;
+  unsigned* w2l = w1l + n_w1l(hid, KS) * 4;
+  const int n1 = (hid / 16) * KS * 64 * 4, n2 = (hid / 32) * OT * 64 * 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
+    unsigned h, m, lo;
+    if (i < n1) {
+      const int d = i & 3, l = (i >> 2) & 63, tk = i >> 8;   // tk = t * KS + ks
+      const int t = tk / KS, ks = tk % KS;
+      const float* src = w1 + (size_t)(16 * t + (l & 15)) * C + 32 * ks + 8 * (l >> 4) + 2 * d;
+      split3_pair(src[0], src[1], h, m, lo);
+      w1hm[((size_t)(tk * 2 + 0) * 64 + l) * 4 + d] = h;
+      w1hm[((size_t)(tk * 2 + 1) * 64 + l) * 4 + d] = m;
+      w1l[((size_t)tk * 64 + l) * 4 + d] = lo;
+    } else {
+      const int k = i - n1;
+      const int d = k & 3, l = (k >> 2) & 63, uo = k >> 8;   // uo = u * OT + ot
+      const int u = uo / OT, ot = uo % OT, g = l >> 4, jj = 2 * d;
+      const int ch = 16 * (2 * u + jj / 4) + 4 * g + jj % 4;
+      const float* src = w2 + (size_t)(16 * ot + (l & 15)) * hid + ch;
+      split3_pair(src[0], src[1], h, m, lo);
+      w2hm[((size_t)((u * 2 + 0) * OT + ot) * 64 + l) * 4 + d] = h;
+      w2hm[((size_t)((u * 2 + 1) * OT + ot) * 64 + l) * 4 + d] = m;
+      w2l[((size_t)uo * 64 + l) * 4 + d] = lo;
+    }
+  }
+}
+
+// six bf16 products per accumulator, smallest terms first: (A part, B part) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+__device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
+
+template <int KS, int OT, bool RESID>
+__global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
+  constexpr int C = 32 * KS;
+  static_assert(OT * 16 == C, "square MLP");
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int ntile = p.hid >> 4, npair = ntile >> 1;
+  u32x4* s_w1 = reinterpret_cast<u32x4*>(smem);        // [ntile][KS][2][64]
+  u32x4* s_w2 = s_w1 + (size_t)ntile * KS * 2 * 64;    // [npair][2][OT][64]
+  float* s_b1 = reinterpret_cast<float*>(s_w2 + (size_t)npair * 2 * OT * 64);
+  {
+    // all loads of a round in flight before the first LDS write (a load -> wait -> write loop took ~90 us for the 128 KB)
+    auto stage = [&](u32x4* dst, const u32x4* src, int n) {
+      for (int base = tid; base < n; base += 8 * (int)blockDim.x) {
+        u32x4 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = base + k * (int)blockDim.x;
+          r[k] = src[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = base + k * (int)blockDim.x;
+          if (i < n) dst[i] = r[k];
+        }
+      }
+    };
+    stage(s_w1, p.w1hm, ntile * KS * 2 * 64);
+    stage(s_w2, p.w2hm, npair * 2 * OT * 64);
+    for (int i = tid; i < p.hid; i += blockDim.x) s_b1[i] = p.b1[i];
+  }
+  __syncthreads();
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (p.trace && blockIdx.x == 0 && lane == 0 && n_stamp < 254) p.trace[wave * 256 + n_stamp++] = __builtin_amdgcn_s_memtime();
+  };
+  if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 256 + 254] = __builtin_amdgcn_s_memrealtime();
+  f32x4 b2v[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+    b2v[ot] = p.b2 ? *reinterpret_cast<const f32x4*>(p.b2 + 16 * ot + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_lo = [&](int u, u32x4(&wl1)[2][KS], u32x4(&wl2)[OT]) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wl1[tt][ks] = p.w1l[((2 * u + tt) * KS + ks) * 64 + lane];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) wl2[ot] = p.w2l[(u * OT + ot) * 64 + lane];
+  };
+  u32x4 la1[2][KS], la2[OT], lb1[2][KS], lb2[OT];
+  load_lo(0, la1, la2);   // unit 0's; every later unit requests its successor's (the last one unit 0's again)
+
+  // Both waves of a SIMD compete for its one vector issue port (an MFMA holds it 8 cycles, a VALU op 4); the
+  // second-dispatched half of the workgroup loses the age-based arbitration on every instruction and finished 40 %
+  // later than the first half (DLWP_TMLP_TRACE: 745k vs 532k cycles).  Static priority for that half evens it out.
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+  const long long npass = (p.T + 31) >> 5;
+  for (long long pass = (long long)blockIdx.x * nw + wave; pass < npass; pass += (long long)gridDim.x * nw) {
+    stamp();
+    long long tok[2];
+    bool live[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const long long t = pass * 32 + 16 * q + j;
+      live[q] = t < p.T;
+      tok[q] = live[q] ? t : p.T - 1;
+    }
+    // layer-1 B operands: the token's channels 32 ks + 8 g .. + 7, split
+    u32x4 bx[2][KS][3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float* src = p.n + tok[q] * C + 32 * ks + 8 * g;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        unsigned hh, mm, ll;
+        split3_pair(v0[0], v0[1], hh, mm, ll); bx[q][ks][0][0] = hh; bx[q][ks][1][0] = mm; bx[q][ks][2][0] = ll;
+        split3_pair(v0[2], v0[3], hh, mm, ll); bx[q][ks][0][1] = hh; bx[q][ks][1][1] = mm; bx[q][ks][2][1] = ll;
+        split3_pair(v1[0], v1[1], hh, mm, ll); bx[q][ks][0][2] = hh; bx[q][ks][1][2] = mm; bx[q][ks][2][2] = ll;
+        split3_pair(v1[2], v1[3], hh, mm, ll); bx[q][ks][0][3] = hh; bx[q][ks][1][3] = mm; bx[q][ks][2][3] = ll;
+      }
+    // the residual is the accumulator's start value: acc2[ot][q][r] = out[token (q, j)][16 ot + 4 g + r]
+    f32x4 acc2[OT][2];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        acc2[ot][q] = b2v[ot];
+        if (RESID) acc2[ot][q] += *reinterpret_cast<const f32x4*>(p.resid + tok[q] * C + 16 * ot + 4 * g);
+      }
+
+    // one hidden-tile pair; the l parts it uses (wl*) were requested one unit ago, those of the next unit (nl*) are
+    // requested at the top so that their L2 latency hides behind this unit's ~1500 matrix-pipe cycles
+    auto unit = [&](int u, const u32x4(&wl1)[2][KS], const u32x4(&wl2)[OT], u32x4(&nl1)[2][KS], u32x4(&nl2)[OT]) {
+      load_lo(u + 1 < npair ? u + 1 : 0, nl1, nl2);
+      // ---- layer 1 of hidden tiles 2u, 2u+1 (4 independent accumulators, term-major so that back-to-back
+      //      MFMAs never depend on each other)
+      f32x4 a1[2][2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * (2 * u + tt) + 4 * g);
+        a1[tt][0] = bb;
+        a1[tt][1] = bb;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 wa[2][3];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int tk = (2 * u + tt) * KS + ks;
+          wa[tt][0] = s_w1[(tk * 2 + 0) * 64 + lane];
+          wa[tt][1] = s_w1[(tk * 2 + 1) * 64 + lane];
+          wa[tt][2] = wl1[tt][ks];
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              a1[tt][q] = mfma16x16x32_bf16(wa[tt][kPA[term]], bx[q][ks][kPB[term]], a1[tt][q]);
+      }
+      // ---- GELU, then the 3-way split straight into layer-2 B operands
+      gelu_erf8_fma(a1[0][0], a1[0][1]);
+      gelu_erf8_fma(a1[1][0], a1[1][1]);
+      u32x4 bg[2][3];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // dword i: k-slots 2i, 2i+1 -> tile i/2, registers 2(i%2), 2(i%2)+1
+          unsigned hh, mm, ll;
+          split3_pair(a1[i / 2][q][2 * (i % 2)], a1[i / 2][q][2 * (i % 2) + 1], hh, mm, ll);
+          bg[q][0][i] = hh;
+          bg[q][1][i] = mm;
+          bg[q][2][i] = ll;
+        }
+      // ---- layer 2: out tiles two at a time
+#pragma unroll
+      for (int oh = 0; oh < OT; oh += 2) {
+        u32x4 wb[2][3];
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo) {
+          wb[oo][0] = s_w2[((u * 2 + 0) * OT + oh + oo) * 64 + lane];
+          wb[oo][1] = s_w2[((u * 2 + 1) * OT + oh + oo) * 64 + lane];
+          wb[oo][2] = wl2[oh + oo];
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int oo = 0; oo < 2; ++oo)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              acc2[oh + oo][q] = mfma16x16x32_bf16(wb[oo][kPA[term]], bg[q][kPB[term]], acc2[oh + oo][q]);
+      }
+    };
+    stamp();
+    for (int u = 0; u < npair; u += 2) {   // npair is even (hidden % 64 == 0): the l-part registers ping-pong
+      unit(u, la1, la2, lb1, lb2);
+      stamp();
+      unit(u + 1, lb1, lb2, la1, la2);
+      stamp();
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (live[q]) *reinterpret_cast<f32x4*>(p.out + tok[q] * C + 16 * ot + 4 * g) = acc2[ot][q];
+  }
+  stamp();
+  if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 256 + 255] = __builtin_amdgcn_s_memrealtime();
+}
+
+}  // namespace tmlp
+}  // namespace dlwp
+
+using namespace dlwp;
+
+static bool token_mlp_shape_ok(int C, int hid, size_t* lds) {
+  if (C != 64 || hid < 64 || hid % 64) return false;
+  const size_t bytes = (tmlp::n_w1hm(hid, C / 32) + tmlp::n_w2hm(hid, C / 16)) * 16 + (size_t)hid * 4;
+  if (lds) *lds = bytes;
+  return bytes <= 160 * 1024;
+}
+
+extern "C" size_t dlwp_token_mlp_packed_bytes(int32_t channels, int32_t hidden) {
+  if (!token_mlp_shape_ok(channels, hidden, nullptr)) return 0;
+  const int KS = channels / 32, OT = channels / 16;
+  return (tmlp::n_w1hm(hidden, KS) + tmlp::n_w2hm(hidden, OT) + tmlp::n_w1l(hidden, KS) + tmlp::n_w2l(hidden, OT)) * 16;
+}
+
+extern "C" int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, int32_t channels, int32_t hidden,
+                                           void* packed_dev, void* stream) {
+  DLWP_REQUIRE(w1_dev && w2_dev && packed_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(token_mlp_shape_ok(channels, hidden, nullptr), DLWP_ERR_UNSUPPORTED,
+               "token MLP: channels %d (64 supported), hidden %d (multiple of 64, <= 256: weights must fit LDS)", channels, hidden);
+  hipLaunchKernelGGL(tmlp::pack_kernel, dim3(64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w1_dev, w2_dev,
+                     reinterpret_cast<unsigned*>(packed_dev), channels, hidden);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev, const void* packed_dev,
+                                      const float* b1_dev, const float* b2_dev, float* out_dev, int64_t tokens,
+                                      int32_t channels, int32_t hidden, void* stream) {
+  DLWP_REQUIRE(n_dev && packed_dev && b1_dev && out_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(tokens > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
+  size_t lds = 0;
+  DLWP_REQUIRE(token_mlp_shape_ok(channels, hidden, &lds), DLWP_ERR_UNSUPPORTED,
+               "token MLP: channels %d (64 supported), hidden %d (multiple of 64, <= 256: weights must fit LDS)", channels, hidden);
+  const int KS = channels / 32, OT = channels / 16;
+  tmlp::Params p;
+  p.n = n_dev;
+  p.resid = resid_dev;
+  p.b2 = b2_dev;
+  p.out = out_dev;
+  const u32x4* base = reinterpret_cast<const u32x4*>(packed_dev);
+  p.w1hm = base;
+  p.w2hm = p.w1hm + tmlp::n_w1hm(hidden, KS);
+  p.w1l = p.w2hm + tmlp::n_w2hm(hidden, OT);
+  p.w2l = p.w1l + tmlp::n_w1l(hidden, KS);
+  p.b1 = b1_dev;
+  p.T = tokens;
+  p.hid = hidden;
+  p.trace = nullptr;
+  static const char* trace_path = getenv("DLWP_TMLP_TRACE");
+  static unsigned long long* trace_buf = nullptr;
+  static int traced = 0;
+  if (trace_path && traced < 2) {
+    if (!trace_buf) DLWP_HIP_CHECK(hipMalloc(&trace_buf, (size_t)8 * 256 * 8));
+    DLWP_HIP_CHECK(hipMemsetAsync(trace_buf, 0, (size_t)8 * 256 * 8, reinterpret_cast<hipStream_t>(stream)));
+    p.trace = trace_buf;
+  }
+  const long long npass = (tokens + 31) / 32;
+  const unsigned grid = (unsigned)(npass < 8 * 256 ? (npass + 7) / 8 : 256);
+  auto kern = resid_dev ? tmlp::token_mlp_kernel<2, 4, true> : tmlp::token_mlp_kernel<2, 4, false>;
+  DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  DLWP_HIP_CHECK(hipGetLastError());
+  if (p.trace) {
+    std::vector<unsigned long long> h((size_t)8 * 256);
+    DLWP_HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    DLWP_HIP_CHECK(hipMemcpy(h.data(), trace_buf, h.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_path, traced ? "a" : "w")) {
+      for (int w = 0; w < 8; ++w) {
+        fprintf(f, "%d %d", traced, w);
+        for (int i = 0; i < 256; ++i) fprintf(f, " %llu", h[(size_t)w * 256 + i]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    ++traced;
+  }
+  return DLWP_OK;
+}

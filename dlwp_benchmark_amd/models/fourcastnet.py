@@ -61,14 +61,24 @@ class _Block(nn.Module):
         self.filter = AFNO2D(dim, num_blocks, sparsity_threshold, hard_thresholding_fraction)
         self.norm2 = ops.HipLayerNorm(dim, eps=1e-6)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self._mlp_packed = ops.TokenMlpWeights()   # derived operand layout, not part of the state dict
+        self._mlp_fused = None
 
     def forward(self, x):
         """fourcastnet.py:180-193 (double skip).  LayerNorm1 writes channels-first for the FFT; the inverse
         layout change is fused with `+ bias`, the first skip and LayerNorm2 (dlwp_afno_merge_f32)."""
         l_cf = ops.layernorm_nhwc_to_nchw(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         f_cf = self.filter.filter_cf(l_cf)
-        # second skip (:192) folded into the fc2 GEMM: the merge kernel stores sum + fc2.bias, addmm adds it (beta = 1)
         m = self.mlp
+        if self._mlp_fused is None:
+            self._mlp_fused = ops.token_mlp_supported(x.shape[-1], m.fc1.out_features)
+        if self._mlp_fused:
+            # fc1 -> GELU -> fc2 -> + second skip (:191-192) in one launch, in place on the merged sum
+            s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return ops.token_mlp(n, s, self._mlp_packed.get(m.fc1.weight, m.fc2.weight), m.fc1.bias, m.fc2.bias,
+                                 m.fc1.out_features, out=s)
+        # other widths: second skip folded into the fc2 GEMM -- the merge kernel stores sum + fc2.bias, addmm adds
+        # onto it (beta = 1)
         s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, sum_bias=m.fc2.bias)
         hid = torch.nn.functional.gelu(torch.nn.functional.linear(n, m.fc1.weight, m.fc1.bias))
         c = x.shape[-1]

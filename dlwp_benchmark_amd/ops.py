@@ -220,6 +220,61 @@ def afno_merge(f_nchw: torch.Tensor, l_nchw: torch.Tensor, x_nhwc: torch.Tensor,
     return s, n
 
 
+def token_mlp_supported(channels: int, hidden: int) -> bool:
+    """True when dlwp_token_mlp_f32 handles this (channels, hidden) pair."""
+    return int(_lib.load().dlwp_token_mlp_packed_bytes(int(channels), int(hidden))) > 0
+
+
+class TokenMlpWeights:
+    """fc1 / fc2 weights of a token MLP in the operand layout of dlwp_token_mlp_f32, re-packed on the device
+    whenever either parameter has been written to (optimizer step, load_state_dict, .to())."""
+
+    def __init__(self):
+        self._key = None
+        self._buf = None
+
+    def get(self, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+        key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version, str(w1.device))
+        if key != self._key:
+            hid, c = w1.shape
+            if tuple(w2.shape) != (c, hid):
+                raise _lib.DlwpError(f"token MLP: fc2.weight {tuple(w2.shape)} does not match fc1.weight {tuple(w1.shape)}")
+            lib = _lib.load()
+            nbytes = int(lib.dlwp_token_mlp_packed_bytes(c, hid))
+            if nbytes == 0:
+                raise _lib.DlwpError(f"token MLP: unsupported shape channels={c} hidden={hid}")
+            buf = torch.empty(nbytes // 4, dtype=torch.int32, device=w1.device)
+            with torch.cuda.device(w1.device):
+                _lib.check(lib.dlwp_token_mlp_pack_f32(w1.detach().contiguous().data_ptr(), w2.detach().contiguous().data_ptr(),
+                                                       c, hid, buf.data_ptr(), _lib.stream_ptr()), "dlwp_token_mlp_pack_f32")
+            self._key, self._buf = key, buf
+        return self._buf
+
+
+def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tensor, b1: torch.Tensor,
+              b2: Optional[torch.Tensor], hidden: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = resid + b2 + fc2(gelu(fc1(n)))  over the last dimension (fourcastnet.py:41-57, :191-192), one launch.
+    `out` may be `resid` itself (in place)."""
+    _lib.require_cuda_tensor(n, "n")
+    n = n.contiguous()
+    c = n.shape[-1]
+    if resid is not None:
+        _lib.require_cuda_tensor(resid, "resid")
+        if resid.shape != n.shape or not resid.is_contiguous():
+            raise _lib.DlwpError("token MLP: resid must be contiguous and shaped like n")
+    if out is None:
+        out = torch.empty_like(n)
+    elif out.shape != n.shape or not out.is_contiguous():
+        raise _lib.DlwpError("token MLP: out must be contiguous and shaped like n")
+    lib = _lib.load()
+    with torch.cuda.device(n.device):
+        _lib.check(lib.dlwp_token_mlp_f32(n.data_ptr(), resid.data_ptr() if resid is not None else None, packed.data_ptr(),
+                                          b1.contiguous().data_ptr(), b2.contiguous().data_ptr() if b2 is not None else None,
+                                          out.data_ptr(), n.numel() // c, c, int(hidden), _lib.stream_ptr()),
+                   "dlwp_token_mlp_f32")
+    return out
+
+
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """LayerNorm over the last dimension (any leading shape)."""
     _lib.require_cuda_tensor(x, "x")

@@ -276,6 +276,22 @@ int32_t dlwp_afno_merge_f32(const float* f_nchw_dev, const float* l_nchw_dev, co
                             float* sum_nhwc_dev, float* norm_nhwc_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
                             void* stream);
 
+/* Token MLP of the AFNO block (reference fourcastnet.py:41-57 `Mlp` = fc1 -> GELU -> fc2, called at :191-192 as
+ * `x = mlp(norm2(x)) + residual`):  out[t] = resid[t] + b2 + W2 gelu(W1 n[t] + b1), all token-major [tokens][channels].
+ * One launch; the [tokens][hidden] activation never reaches memory (both GEMMs on the bf16 matrix pipe as six-term
+ * exact splits = fp32-GEMM accuracy).  channels == 64, hidden % 64 == 0, hidden <= 256 (weights are LDS resident);
+ * anything else returns DLWP_ERR_UNSUPPORTED and the caller keeps its GEMM path.
+ *   dlwp_token_mlp_packed_bytes: size of the packed-weight buffer (0 if the shape is unsupported)
+ *   dlwp_token_mlp_pack_f32:     w1_dev [hidden][channels] (fc1.weight), w2_dev [channels][hidden] (fc2.weight) -> packed
+ *   dlwp_token_mlp_f32:          resid_dev, b2_dev may be NULL; out_dev may alias resid_dev (each element is read
+ *                                before it is written, by the same lane). */
+size_t dlwp_token_mlp_packed_bytes(int32_t channels, int32_t hidden);
+int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, int32_t channels, int32_t hidden,
+                                void* packed_dev, void* stream);
+int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev, const void* packed_dev, const float* b1_dev,
+                           const float* b2_dev, float* out_dev, int64_t tokens, int32_t channels, int32_t hidden,
+                           void* stream);
+
 /* On-device evaluation sums (reference scripts/evaluate.py:786-821 `compute_metrics` + the
  * de-normalisation of :281-296): out_dev, target_dev [B, K, C, H, W]; climatology_dev [K, C, H, W] or NULL;
  * lat_weights_dev [H] (cos(lat)/mean(cos(lat))); scale_dev [C] (per-variable std) or NULL.

@@ -1,0 +1,74 @@
+"""GPU parity of the fused token MLP (dlwp_token_mlp_f32) with the ops it replaces in the AFNO block
+(reference fourcastnet.py:41-57 `Mlp` and the second skip of :191-192): fc1 -> exact GELU -> fc2 -> + residual.
+
+Checker: the same expression in float64 torch on the device.  Tolerance 2e-6 relative L2 / 1e-5 of the output scale per
+element: the kernel evaluates both GEMMs as six-term exact bf16 splits with fp32 accumulation, i.e. at fp32-GEMM
+accuracy, and the model-level fixtures from the real reference (test_backbones_gpu.py, test_fullsize_gpu.py) run
+through it at the 1e-5 per-step bound."""
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(n, resid, w1, b1, w2, b2):
+    h = torch.nn.functional.gelu(torch.nn.functional.linear(n.double(), w1.double(), b1.double()))
+    y = torch.nn.functional.linear(h, w2.double(), b2.double() if b2 is not None else None)
+    return y + resid.double() if resid is not None else y
+
+
+@pytest.mark.parametrize("tokens,hidden,use_resid,use_b2", [(4096, 256, True, True), (1000, 256, True, False),
+                                                            (33, 64, False, True), (32 * 700 + 5, 192, True, True)])
+def test_token_mlp_matches_fp64(tokens, hidden, use_resid, use_b2):
+    from dlwp_benchmark_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(1234 + tokens)
+    c = 64
+    n = torch.randn(tokens, c, generator=gen).to(dev)
+    resid = (3.0 * torch.randn(tokens, c, generator=gen)).to(dev) if use_resid else None
+    w1 = (torch.randn(hidden, c, generator=gen) / c ** 0.5).to(dev)
+    b1 = (0.3 * torch.randn(hidden, generator=gen)).to(dev)
+    w2 = (torch.randn(c, hidden, generator=gen) / hidden ** 0.5).to(dev)
+    b2 = (0.3 * torch.randn(c, generator=gen)).to(dev) if use_b2 else None
+    assert ops.token_mlp_supported(c, hidden)
+    packed = ops.TokenMlpWeights()
+    got = ops.token_mlp(n, resid, packed.get(w1, w2), b1, b2, hidden)
+    want = _reference(n, resid, w1, b1, w2, b2)
+    assert rel_l2(got.double().cpu(), want.cpu()) < 2e-6
+    assert (got.double() - want).abs().max().item() < 1e-5 * want.abs().max().item()
+    if resid is not None:   # in place on the residual, as the AFNO block calls it
+        r2 = resid.clone()
+        out = ops.token_mlp(n, r2, packed.get(w1, w2), b1, b2, hidden, out=r2)
+        assert out.data_ptr() == r2.data_ptr()
+        assert torch.equal(out, got)
+
+
+def test_token_mlp_repacks_after_weight_update():
+    from dlwp_benchmark_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    n = torch.randn(256, 64, generator=gen).to(dev)
+    w1 = torch.nn.Parameter((torch.randn(256, 64, generator=gen) / 8).to(dev))
+    w2 = torch.nn.Parameter((torch.randn(64, 256, generator=gen) / 16).to(dev))
+    b1 = torch.zeros(256, device=dev)
+    packed = ops.TokenMlpWeights()
+    a = ops.token_mlp(n, None, packed.get(w1, w2), b1, None, 256)
+    with torch.no_grad():
+        w2.mul_(2.0)
+    b = ops.token_mlp(n, None, packed.get(w1, w2), b1, None, 256)
+    assert rel_l2(b.cpu(), (2.0 * a).cpu()) < 1e-6
+
+
+def test_token_mlp_rejects_unsupported_width():
+    from dlwp_benchmark_amd import lib as _lib
+    from dlwp_benchmark_amd import ops
+
+    assert not ops.token_mlp_supported(96, 384)
+    assert not ops.token_mlp_supported(64, 320)   # weights would not fit LDS
+    assert not ops.token_mlp_supported(64, 96)
+    with pytest.raises(_lib.DlwpError):
+        ops.TokenMlpWeights().get(torch.zeros(384, 96, device="cuda:0"), torch.zeros(96, 384, device="cuda:0"))
