@@ -31,6 +31,7 @@ struct Params {
   int B, H, Wf, C, nb;
   int row_lo, row_hi, km;   // kept rows [row_lo, row_hi), kept cols [0, km)
   float lambd;
+  float in_scale, out_scale;   // y = out_scale * mix(in_scale * x): the "ortho" factors of unnormalised transforms
 };
 
 __device__ __forceinline__ float softshrink(float v, float l) { return v > l ? v - l : (v < -l ? v + l : 0.f); }
@@ -51,7 +52,10 @@ __global__ __launch_bounds__(256) void afno_mix_kernel(const Params p) {
       if (kept_row) {
         float2 xin[BS];
 #pragma unroll
-        for (int i = 0; i < BS; ++i) xin[i] = p.x[base + (long long)(blk * BS + i) * plane + jcol];
+        for (int i = 0; i < BS; ++i) {
+          const float2 v = p.x[base + (long long)(blk * BS + i) * plane + jcol];
+          xin[i] = float2{v.x * p.in_scale, v.y * p.in_scale};
+        }
         const float* w1r = p.w1 + (long long)blk * BS * BS;
         const float* w1i = w1r + (long long)p.nb * BS * BS;
         float2 h1[BS];
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void afno_mix_kernel(const Params p) {
             ar = fmaf(h1[i].x, r, fmaf(-h1[i].y, im, ar));
             ai = fmaf(h1[i].y, r, fmaf(h1[i].x, im, ai));
           }
-          out[o] = float2{softshrink(ar, p.lambd), softshrink(ai, p.lambd)};
+          out[o] = float2{softshrink(ar, p.lambd) * p.out_scale, softshrink(ai, p.lambd) * p.out_scale};
         }
       } else {
 #pragma unroll
@@ -156,7 +160,11 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
       // ---- layer 1
       float2 xin[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xin[s] = live ? p.x[base + (long long)(blk * BS + 4 * s + g) * plane] : float2{0.f, 0.f};
+      for (int s = 0; s < 4; ++s) {
+        xin[s] = live ? p.x[base + (long long)(blk * BS + 4 * s + g) * plane] : float2{0.f, 0.f};
+        xin[s].x *= p.in_scale;
+        xin[s].y *= p.in_scale;
+      }
       f32x4 d1[2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           p.y[base + (long long)(blk * BS + 4 * g + r) * plane] =
-              float2{softshrink(d2[0][r], p.lambd), softshrink(d2[1][r], p.lambd)};
+              float2{softshrink(d2[0][r], p.lambd) * p.out_scale, softshrink(d2[1][r], p.lambd) * p.out_scale};
       }
     }
   }
@@ -199,10 +207,11 @@ __global__ __launch_bounds__(256) void afno_zero_fill_kernel(const Params p) {
 
 using namespace dlwp;
 
-extern "C" int32_t dlwp_afno2d_mix_f32(const float* xf, float* yf, const float* w1, const float* b1, const float* w2,
-                                       const float* b2, int32_t batch, int32_t H, int32_t Wf, int32_t C,
-                                       int32_t num_blocks, float sparsity_threshold, float hard_thresholding_fraction,
-                                       void* stream) {
+extern "C" int32_t dlwp_afno2d_mix_scaled_f32(const float* xf, float* yf, const float* w1, const float* b1,
+                                              const float* w2, const float* b2, int32_t batch, int32_t H, int32_t Wf,
+                                              int32_t C, int32_t num_blocks, float sparsity_threshold,
+                                              float hard_thresholding_fraction, float in_scale, float out_scale,
+                                              void* stream) {
   DLWP_REQUIRE(xf && yf && w1 && b1 && w2 && b2, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0 && H > 0 && Wf > 0 && C > 0 && num_blocks > 0 && C % num_blocks == 0, DLWP_ERR_INVALID_ARGUMENT,
                "bad shape");
@@ -219,6 +228,8 @@ extern "C" int32_t dlwp_afno2d_mix_f32(const float* xf, float* yf, const float* 
   p.row_hi = total + kept > H ? H : total + kept;
   p.km = kept > Wf ? Wf : kept;
   p.lambd = sparsity_threshold;
+  p.in_scale = in_scale;
+  p.out_scale = out_scale;
   const long long npts = (long long)batch * H * p.km;
   long long blocks = (npts + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
@@ -240,4 +251,12 @@ extern "C" int32_t dlwp_afno2d_mix_f32(const float* xf, float* yf, const float* 
   }
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_afno2d_mix_f32(const float* xf, float* yf, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, int32_t batch, int32_t H, int32_t Wf, int32_t C,
+                                       int32_t num_blocks, float sparsity_threshold, float hard_thresholding_fraction,
+                                       void* stream) {
+  return dlwp_afno2d_mix_scaled_f32(xf, yf, w1, b1, w2, b2, batch, H, Wf, C, num_blocks, sparsity_threshold,
+                                    hard_thresholding_fraction, 1.0f, 1.0f, stream);
 }

@@ -68,6 +68,12 @@ SIGNATURES = {
     "dlwp_window_attn_bf16": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "dlwp_afno2d_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
+    "dlwp_afno2d_mix_scaled_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                             c_int32, c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p]),
+    "dlwp_fft2_plan_create": (c_int32, [ctypes.POINTER(c_void_p), c_int32, c_int32, c_int32]),
+    "dlwp_fft2_plan_destroy": (c_int32, [c_void_p]),
+    "dlwp_rfft2_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dlwp_irfft2_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "dlwp_conv3x3_cyl_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dlwp_conv3x3_hpx_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,

@@ -42,11 +42,8 @@ class AFNO2D(nn.Module):
 
     def filter_cf(self, x_cf):
         """x_cf CHANNELS-FIRST [B, C, H, W] -> irfft2(mix(rfft2(x_cf))) (without the `+ bias` of :127)."""
-        h, w = x_cf.shape[-2], x_cf.shape[-1]
-        xf = torch.fft.rfft2(x_cf, norm="ortho")
-        yf = ops.afno2d_mix(xf, self.w1, self.b1, self.w2, self.b2, self.num_blocks, self.sparsity_threshold,
-                            self.hard_thresholding_fraction)
-        return torch.fft.irfft2(yf, s=(h, w), norm="ortho")
+        return ops.afno2d_filter_cf(x_cf, self.w1, self.b1, self.w2, self.b2, self.num_blocks, self.sparsity_threshold,
+                                    self.hard_thresholding_fraction)
 
     def forward(self, x):
         """x [B, H, W, C] -> irfft2(mix(rfft2(x))) + x   (fourcastnet.py:78-127)"""

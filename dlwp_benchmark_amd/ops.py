@@ -187,6 +187,52 @@ def afno2d_mix(xf_cf: torch.Tensor, w1, b1, w2, b2, num_blocks: int, sparsity_th
     return torch.view_as_complex(yr)
 
 
+class _Fft2Plans:
+    """hipFFT plan pairs (R2C + C2R) per (device, batch, H, W), created on first use and kept for the process."""
+
+    def __init__(self):
+        self._plans = {}
+
+    def get(self, device, batch: int, h: int, w: int):
+        key = (str(device), batch, h, w)
+        if key not in self._plans:
+            lib = _lib.load()
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.dlwp_fft2_plan_create(ctypes.byref(handle), batch, h, w), "dlwp_fft2_plan_create")
+            self._plans[key] = handle
+        return self._plans[key]
+
+
+_fft2_plans = _Fft2Plans()
+
+
+def afno2d_filter_cf(x_cf: torch.Tensor, w1, b1, w2, b2, num_blocks: int, sparsity_threshold: float,
+                     hard_thresholding_fraction: float) -> torch.Tensor:
+    """irfft2(mix(rfft2(x_cf, norm="ortho")), norm="ortho") for CHANNELS-FIRST x_cf [B, C, H, W]
+    (fourcastnet.py:87-123 without the `+ bias` of :127): unnormalised hipFFT transforms, the two 1/sqrt(HW)
+    factors inside the mixing kernel, the spectrum mixed in place -- three launches + rocFFT's own kernels."""
+    _lib.require_cuda_tensor(x_cf, "x_cf")
+    x_cf = x_cf.contiguous()
+    b, c, h, w = x_cf.shape
+    wf = w // 2 + 1
+    spec = torch.empty(b, c, h, wf, 2, device=x_cf.device, dtype=torch.float32)
+    y = torch.empty_like(x_cf)
+    lib = _lib.load()
+    plan = _fft2_plans.get(x_cf.device, b * c, h, w)
+    scale = 1.0 / float(h * w) ** 0.5
+    with torch.cuda.device(x_cf.device):
+        st = _lib.stream_ptr()
+        _lib.check(lib.dlwp_rfft2_f32(plan, x_cf.data_ptr(), spec.data_ptr(), st), "dlwp_rfft2_f32")
+        _lib.check(lib.dlwp_afno2d_mix_scaled_f32(spec.data_ptr(), spec.data_ptr(), w1.contiguous().data_ptr(),
+                                                  b1.contiguous().data_ptr(), w2.contiguous().data_ptr(),
+                                                  b2.contiguous().data_ptr(), b, h, wf, c, num_blocks,
+                                                  float(sparsity_threshold), float(hard_thresholding_fraction),
+                                                  scale, scale, st), "dlwp_afno2d_mix_scaled_f32")
+        _lib.check(lib.dlwp_irfft2_f32(plan, spec.data_ptr(), y.data_ptr(), st), "dlwp_irfft2_f32")
+    return y
+
+
 def layernorm_nhwc_to_nchw(x: torch.Tensor, weight, bias, eps: float) -> torch.Tensor:
     """x [B, H, W, C] -> LayerNorm over C, returned channels-first [B, C, H, W]."""
     _lib.require_cuda_tensor(x, "x")

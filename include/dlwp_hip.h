@@ -217,6 +217,25 @@ int32_t dlwp_afno2d_mix_f32(const float* xf_dev, float* yf_dev, const float* w1_
                             const float* w2_dev, const float* b2_dev, int32_t batch, int32_t height,
                             int32_t wf, int32_t channels, int32_t num_blocks, float sparsity_threshold,
                             float hard_thresholding_fraction, void* stream);
+/* Same with yf = out_scale * mix(in_scale * xf): lets the caller use UNNORMALISED transforms (below) and still get
+ * the reference's norm="ortho" arithmetic (:87, :122; in_scale = out_scale = 1/sqrt(H*W)) without two elementwise
+ * passes over the spectrum.  yf_dev may be xf_dev (in place): a point's channels are read before they are written and
+ * no other point is read by the thread that writes it. */
+int32_t dlwp_afno2d_mix_scaled_f32(const float* xf_dev, float* yf_dev, const float* w1_dev, const float* b1_dev,
+                                   const float* w2_dev, const float* b2_dev, int32_t batch, int32_t height,
+                                   int32_t wf, int32_t channels, int32_t num_blocks, float sparsity_threshold,
+                                   float hard_thresholding_fraction, float in_scale, float out_scale, void* stream);
+
+/* Batched unnormalised 2-D real FFTs of `batch` contiguous [H, W] planes (reference fourcastnet.py:87
+ * `torch.fft.rfft2(x, dim=(1, 2))` and :122-123 `irfft2`, applied channels-first so that batch = B * C) through
+ * hipFFT, without the clone, layout copies and scaling pass torch.fft adds per call.
+ *   dlwp_rfft2_f32:  x_dev [batch][H][W] -> xf_dev [batch][H][W/2+1][2]
+ *   dlwp_irfft2_f32: yf_dev [batch][H][W/2+1][2] -> y_dev [batch][H][W]; yf_dev is DESTROYED (C2R scratch). */
+typedef struct dlwp_fft2_plan dlwp_fft2_plan;
+int32_t dlwp_fft2_plan_create(dlwp_fft2_plan** out, int32_t batch, int32_t height, int32_t width);
+int32_t dlwp_fft2_plan_destroy(dlwp_fft2_plan* plan);
+int32_t dlwp_rfft2_f32(const dlwp_fft2_plan* plan, const float* x_dev, float* xf_dev, void* stream);
+int32_t dlwp_irfft2_f32(const dlwp_fft2_plan* plan, float* yf_dev, float* y_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CylinderPad(1) + Conv2d(3x3, padding 0) + bias + activation, input optionally given as two
