@@ -120,9 +120,15 @@ class FourCastNet(HipBackbone):
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:
         b = x.shape[0]
-        x = self.patch_embed(x)
-        if self.use_pos_embed:
-            x = x + self.pos_embed
+        proj = self.patch_embed.proj
+        if self.patch_size == (1, 1) and ops.patch_embed_1x1_supported(proj.in_channels, self.embed_dim):
+            if tuple(x.shape[2:]) != self.img_size:
+                raise _lib.DlwpError(f"Input image size {tuple(x.shape[2:])} doesn't match model {self.img_size}")
+            x = ops.patch_embed_1x1(x, proj.weight, proj.bias, self.pos_embed[0] if self.use_pos_embed else None)
+        else:
+            x = self.patch_embed(x)   # a transposed view: materialise token-major ONCE, with the add
+            tok = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+            x = torch.add(x, self.pos_embed, out=tok) if self.use_pos_embed else tok.copy_(x)
         x = x.reshape(b, self.h, self.w, self.embed_dim)
         for blk in self.blocks:
             x = blk(x)

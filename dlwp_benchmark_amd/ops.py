@@ -266,6 +266,30 @@ def afno_merge(f_nchw: torch.Tensor, l_nchw: torch.Tensor, x_nhwc: torch.Tensor,
     return s, n
 
 
+def patch_embed_1x1_supported(in_channels: int, channels: int) -> bool:
+    return in_channels <= 32 and 4 <= channels <= 256 and channels & (channels - 1) == 0
+
+
+def patch_embed_1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                    pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """x [B, Cin, H, W], weight [C, Cin, 1, 1] (Conv2d with 1x1 patches), pos [H*W, C] or None ->
+    tokens [B, H*W, C] = conv(x).flatten(2).transpose(1, 2) + pos   (fourcastnet.py:530-543, :286-288)."""
+    _lib.require_cuda_tensor(x, "x")
+    x = x.contiguous()
+    b, cin, h, w = x.shape
+    c = weight.shape[0]
+    if pos is not None and (tuple(pos.shape) != (h * w, c) or not pos.is_contiguous()):
+        raise _lib.DlwpError(f"patch embed: pos must be contiguous [{h * w}, {c}], got {tuple(pos.shape)}")
+    out = torch.empty(b, h * w, c, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_patch_embed_1x1_f32(x.data_ptr(), weight.contiguous().data_ptr(),
+                                                bias.contiguous().data_ptr() if bias is not None else None,
+                                                pos.data_ptr() if pos is not None else None, out.data_ptr(), b, cin,
+                                                h * w, c, _lib.stream_ptr()), "dlwp_patch_embed_1x1_f32")
+    return out
+
+
 def token_mlp_supported(channels: int, hidden: int) -> bool:
     """True when dlwp_token_mlp_f32 handles this (channels, hidden) pair."""
     return int(_lib.load().dlwp_token_mlp_packed_bytes(int(channels), int(hidden))) > 0

@@ -295,6 +295,16 @@ int32_t dlwp_afno_merge_f32(const float* f_nchw_dev, const float* l_nchw_dev, co
                             float* sum_nhwc_dev, float* norm_nhwc_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
                             void* stream);
 
+/* Patch embedding for 1x1 patches + position embedding (reference fourcastnet.py:530-543 `PatchEmbed` =
+ * Conv2d(kernel = stride = patch) -> flatten(2).transpose(1, 2), and `x + pos_embed` at :286-288) in one pass:
+ *   out[b][t][c] = bias[c] + pos[t][c] + sum_ci w[c][ci] x[b][ci][t]
+ * x_dev [batch][in_channels][tokens] (NCHW with tokens = H*W), w_dev [channels][in_channels] (the conv weight with its
+ * 1x1 kernel dims dropped), bias_dev [channels] or NULL, pos_dev [tokens][channels] or NULL, out_dev token-major.
+ * in_channels <= 32, channels a power of two in [4, 256]; other shapes: DLWP_ERR_UNSUPPORTED. */
+int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_dev, const float* bias_dev, const float* pos_dev,
+                                 float* out_dev, int32_t batch, int32_t in_channels, int64_t tokens, int32_t channels,
+                                 void* stream);
+
 /* Token MLP of the AFNO block (reference fourcastnet.py:41-57 `Mlp` = fc1 -> GELU -> fc2, called at :191-192 as
  * `x = mlp(norm2(x)) + residual`):  out[t] = resid[t] + b2 + W2 gelu(W1 n[t] + b1), all token-major [tokens][channels].
  * One launch; the [tokens][hidden] activation never reaches memory (both GEMMs on the bf16 matrix pipe as six-term

@@ -33,3 +33,22 @@ def test_filter_matches_torch_fft_path(shape, nb, frac):
     # the input must survive (only the internal spectrum buffer is scratch for the C2R transform)
     again = ops.afno2d_filter_cf(x, w1, b1, w2, b2, nb, lam, frac)
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("b,cin,h,w,c,use_pos", [(2, 8, 16, 32, 64, True), (3, 18, 5, 7, 32, False), (1, 1, 8, 8, 16, True)])
+def test_patch_embed_1x1_matches_conv(b, cin, h, w, c, use_pos):
+    """dlwp_patch_embed_1x1_f32 vs Conv2d(1x1) -> flatten(2).transpose(1, 2) -> + pos_embed (fourcastnet.py:530-543)."""
+    from dlwp_benchmark_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(b, cin, h, w, generator=gen).to(dev)
+    wt = torch.randn(c, cin, 1, 1, generator=gen).to(dev)
+    bias = torch.randn(c, generator=gen).to(dev)
+    pos = torch.randn(h * w, c, generator=gen).to(dev) if use_pos else None
+    got = ops.patch_embed_1x1(x, wt, bias, pos)
+    want = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double()).flatten(2).transpose(1, 2)
+    if use_pos:
+        want = want + pos.double()
+    assert got.shape == want.shape and got.is_contiguous()
+    assert rel_l2(got, want) < 1e-6
