@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void afno_merge_kernel(const float* __restrict
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int iv = sub + 16 * v;
-    gm[v] = iv < nvec ? *reinterpret_cast<const f32x4*>(gamma + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
-    bt[v] = iv < nvec ? *reinterpret_cast<const f32x4*>(beta + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
+    gm[v] = (n_out && iv < nvec) ? *reinterpret_cast<const f32x4*>(gamma + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bt[v] = (n_out && iv < nvec) ? *reinterpret_cast<const f32x4*>(beta + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   f32x4 sb[NV];   // optional per-channel constant added to the STORED sum only (not to the LayerNorm input)
 #pragma unroll
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void afno_merge_kernel(const float* __restrict
         }
         s += (sv[v][0] + sv[v][1]) + (sv[v][2] + sv[v][3]);
       }
+      if (!n_out) continue;   // caller normalises downstream (dlwp_token_mlp_f32 with ln_eps >= 0)
 #pragma unroll
       for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m);
       const float mean = s * inv_c;
@@ -311,7 +312,8 @@ extern "C" int32_t dlwp_layernorm_nhwc_to_nchw_f32(const float* x, const float* 
 extern "C" int32_t dlwp_afno_merge_f32(const float* f_nchw, const float* l_nchw, const float* x_nhwc, const float* gamma,
                                        const float* beta, const float* sum_bias, float* sum_nhwc, float* norm_nhwc,
                                        int32_t batch, int64_t tokens, int32_t channels, float eps, void* stream) {
-  DLWP_REQUIRE(f_nchw && l_nchw && x_nhwc && gamma && beta && sum_nhwc && norm_nhwc, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(f_nchw && l_nchw && x_nhwc && sum_nhwc && (!norm_nhwc || (gamma && beta)), DLWP_ERR_INVALID_ARGUMENT,
+               "null argument");
   DLWP_REQUIRE(batch > 0 && tokens > 0 && channels > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
   DLWP_REQUIRE(channels % 4 == 0 && channels <= 256, DLWP_ERR_UNSUPPORTED, "channels %d: multiple of 4, <= 256", channels);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -30,6 +30,7 @@ struct Params {
   const float* b1;      // [hid]
   long long T;
   int hid;
+  float ln_eps;         // LN variant: n is the un-normalised token, LayerNorm (affine folded into W1 / b1) happens here
   unsigned long long* trace;   // diagnostics (DLWP_TMLP_TRACE): [wave of workgroup 0][256] s_memtime stamps, or null
 };
 
@@ -39,8 +40,12 @@ __host__ __device__ inline size_t n_w2hm(int hid, int OT) { return (size_t)(hid 
 __host__ __device__ inline size_t n_w1l(int hid, int KS) { return (size_t)(hid / 16) * KS * 64; }
 __host__ __device__ inline size_t n_w2l(int hid, int OT) { return (size_t)(hid / 32) * OT * 64; }
 
+// gamma / beta (both or neither): the affine part of a LayerNorm in front of fc1 is folded into the operands,
+//   W1 (gamma * xhat + beta) + b1 = (W1 diag(gamma)) xhat + (b1 + W1 beta);  the folded bias lands behind w2l.
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
-                                                   unsigned* __restrict__ dst, int C, int hid) {
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ b1, unsigned* __restrict__ dst, int C,
+                                                   int hid) {
   const int KS = C / 32, OT = C / 16;
   unsigned* w1hm = dst;
   unsigned* w2hm = w1hm + n_w1hm(hid, KS) * 4;
@@ -52,8 +57,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
     if (i < n1) {
       const int d = i & 3, l = (i >> 2) & 63, tk = i >> 8;   // tk = t * KS + ks
       const int t = tk / KS, ks = tk % KS;
-      const float* src = w1 + (size_t)(16 * t + (l & 15)) * C + 32 * ks + 8 * (l >> 4) + 2 * d;
-      split3_pair(src[0], src[1], h, m, lo);
+      const int ch = 32 * ks + 8 * (l >> 4) + 2 * d;
+      const float* src = w1 + (size_t)(16 * t + (l & 15)) * C + ch;
+      split3_pair(gamma ? src[0] * gamma[ch] : src[0], gamma ? src[1] * gamma[ch + 1] : src[1], h, m, lo);
       w1hm[((size_t)(tk * 2 + 0) * 64 + l) * 4 + d] = h;
       w1hm[((size_t)(tk * 2 + 1) * 64 + l) * 4 + d] = m;
       w1l[((size_t)tk * 64 + l) * 4 + d] = lo;
@@ -69,13 +75,21 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
       w2l[((size_t)uo * 64 + l) * 4 + d] = lo;
     }
   }
+  if (gamma) {
+    float* b1f = reinterpret_cast<float*>(w2l + n_w2l(hid, OT) * 4);
+    for (int hrow = blockIdx.x * blockDim.x + threadIdx.x; hrow < hid; hrow += gridDim.x * blockDim.x) {
+      float a = b1 ? b1[hrow] : 0.f;
+      for (int c = 0; c < C; ++c) a = fmaf(w1[(size_t)hrow * C + c], beta[c], a);
+      b1f[hrow] = a;
+    }
+  }
 }
 
 // six bf16 products per accumulator, smallest terms first: (A part, B part) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
 __device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
 
-template <int KS, int OT, bool RESID>
+template <int KS, int OT, bool RESID, bool LN>
 __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   constexpr int C = 32 * KS;
   static_assert(OT * 16 == C, "square MLP");
@@ -83,9 +97,12 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int ntile = p.hid >> 4, npair = ntile >> 1;
+  const unsigned long long rt_entry = p.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   u32x4* s_w1 = reinterpret_cast<u32x4*>(smem);        // [ntile][KS][2][64]
   u32x4* s_w2 = s_w1 + (size_t)ntile * KS * 2 * 64;    // [npair][2][OT][64]
   float* s_b1 = reinterpret_cast<float*>(s_w2 + (size_t)npair * 2 * OT * 64);
+  int* s_next = reinterpret_cast<int*>(s_b1 + p.hid);   // the workgroup's pass counter
+  if (tid == 0) *s_next = 0;
   {
     // all loads of a round in flight before the first LDS write (a load -> wait -> write loop took ~90 us for the 128 KB)
     auto stage = [&](u32x4* dst, const u32x4* src, int n) {
@@ -110,9 +127,12 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   __syncthreads();
   int n_stamp = 0;
   auto stamp = [&]() {
-    if (p.trace && blockIdx.x == 0 && lane == 0 && n_stamp < 254) p.trace[wave * 256 + n_stamp++] = __builtin_amdgcn_s_memtime();
+    if (p.trace && blockIdx.x == 0 && lane == 0 && n_stamp < 253) p.trace[wave * 256 + n_stamp++] = __builtin_amdgcn_s_memtime();
   };
-  if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 256 + 254] = __builtin_amdgcn_s_memrealtime();
+  if (p.trace && blockIdx.x == 0 && lane == 0) {
+    p.trace[wave * 256 + 253] = rt_entry;
+    p.trace[wave * 256 + 254] = __builtin_amdgcn_s_memrealtime();
+  }
   f32x4 b2v[OT];
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot)
@@ -129,13 +149,19 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   u32x4 la1[2][KS], la2[OT], lb1[2][KS], lb2[OT];
   load_lo(0, la1, la2);   // unit 0's; every later unit requests its successor's (the last one unit 0's again)
 
-  // Both waves of a SIMD compete for its one vector issue port (an MFMA holds it 8 cycles, a VALU op 4); the
-  // second-dispatched half of the workgroup loses the age-based arbitration on every instruction and finished 40 %
-  // later than the first half (DLWP_TMLP_TRACE: 745k vs 532k cycles).  Static priority for that half evens it out.
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-
+  // Passes are handed out dynamically inside the workgroup: the older wave of a SIMD wins the issue arbitration and
+  // runs ~1.5x faster than its partner (DLWP_TMLP_TRACE: 3.9k vs 5.4k cycles per tile pair), and a wave left alone
+  // on its SIMD cannot overlap its own MFMA bursts with its GELU -- with a static split the fast half idled through
+  // the last 25 % of the kernel.
   const long long npass = (p.T + 31) >> 5;
-  for (long long pass = (long long)blockIdx.x * nw + wave; pass < npass; pass += (long long)gridDim.x * nw) {
+  const long long per_wg = (npass + gridDim.x - 1) / gridDim.x;
+  const long long pass_lo = (long long)blockIdx.x * per_wg;
+  const long long pass_hi = pass_lo + per_wg < npass ? pass_lo + per_wg : npass;
+  for (;;) {
+    int mine = 0;
+    if (lane == 0) mine = atomicAdd(s_next, 1);
+    const long long pass = pass_lo + __builtin_amdgcn_readfirstlane(mine);
+    if (pass >= pass_hi) break;
     stamp();
     long long tok[2];
     bool live[2];
@@ -145,20 +171,56 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
       live[q] = t < p.T;
       tok[q] = live[q] ? t : p.T - 1;
     }
-    // layer-1 B operands: the token's channels 32 ks + 8 g .. + 7, split
+    // layer-1 B operands: the token's channels 32 ks + 8 g .. + 7 (LayerNorm'd here in the LN variant: the four g lanes
+    // of a token hold its C channels between them; two-pass statistics like torch), split
     u32x4 bx[2][KS][3];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+      f32x4 v[KS][2];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const float* src = p.n + tok[q] * C + 32 * ks + 8 * g;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-        unsigned hh, mm, ll;
-        split3_pair(v0[0], v0[1], hh, mm, ll); bx[q][ks][0][0] = hh; bx[q][ks][1][0] = mm; bx[q][ks][2][0] = ll;
-        split3_pair(v0[2], v0[3], hh, mm, ll); bx[q][ks][0][1] = hh; bx[q][ks][1][1] = mm; bx[q][ks][2][1] = ll;
-        split3_pair(v1[0], v1[1], hh, mm, ll); bx[q][ks][0][2] = hh; bx[q][ks][1][2] = mm; bx[q][ks][2][2] = ll;
-        split3_pair(v1[2], v1[3], hh, mm, ll); bx[q][ks][0][3] = hh; bx[q][ks][1][3] = mm; bx[q][ks][2][3] = ll;
+        v[ks][0] = *reinterpret_cast<const f32x4*>(src);
+        v[ks][1] = *reinterpret_cast<const f32x4*>(src + 4);
       }
+      if (LN) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) sum += (v[ks][hh][0] + v[ks][hh][1]) + (v[ks][hh][2] + v[ks][hh][3]);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[ks][hh][k] -= mean;
+              sq = fmaf(v[ks][hh][k], v[ks][hh][k], sq);
+            }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / C) + p.ln_eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) v[ks][hh] *= rstd;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned hh, mm, ll;
+          split3_pair(v[ks][i / 2][2 * (i % 2)], v[ks][i / 2][2 * (i % 2) + 1], hh, mm, ll);
+          bx[q][ks][0][i] = hh;
+          bx[q][ks][1][i] = mm;
+          bx[q][ks][2][i] = ll;
+        }
+    }
     // the residual is the accumulator's start value: acc2[ot][q][r] = out[token (q, j)][16 ot + 4 g + r]
     f32x4 acc2[OT][2];
 #pragma unroll
@@ -257,7 +319,7 @@ using namespace dlwp;
 
 static bool token_mlp_shape_ok(int C, int hid, size_t* lds) {
   if (C != 64 || hid < 64 || hid % 64) return false;
-  const size_t bytes = (tmlp::n_w1hm(hid, C / 32) + tmlp::n_w2hm(hid, C / 16)) * 16 + (size_t)hid * 4;
+  const size_t bytes = (tmlp::n_w1hm(hid, C / 32) + tmlp::n_w2hm(hid, C / 16)) * 16 + (size_t)hid * 4 + 16;
   if (lds) *lds = bytes;
   return bytes <= 160 * 1024;
 }
@@ -265,24 +327,29 @@ static bool token_mlp_shape_ok(int C, int hid, size_t* lds) {
 extern "C" size_t dlwp_token_mlp_packed_bytes(int32_t channels, int32_t hidden) {
   if (!token_mlp_shape_ok(channels, hidden, nullptr)) return 0;
   const int KS = channels / 32, OT = channels / 16;
-  return (tmlp::n_w1hm(hidden, KS) + tmlp::n_w2hm(hidden, OT) + tmlp::n_w1l(hidden, KS) + tmlp::n_w2l(hidden, OT)) * 16;
+  return (tmlp::n_w1hm(hidden, KS) + tmlp::n_w2hm(hidden, OT) + tmlp::n_w1l(hidden, KS) + tmlp::n_w2l(hidden, OT)) * 16 +
+         (size_t)hidden * 4;   // + the folded fc1 bias of the LayerNorm variant
 }
 
-extern "C" int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, int32_t channels, int32_t hidden,
-                                           void* packed_dev, void* stream) {
+extern "C" int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
+                                           const float* ln_beta_dev, const float* b1_dev, int32_t channels,
+                                           int32_t hidden, void* packed_dev, void* stream) {
   DLWP_REQUIRE(w1_dev && w2_dev && packed_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE((ln_gamma_dev == nullptr) == (ln_beta_dev == nullptr), DLWP_ERR_INVALID_ARGUMENT,
+               "LayerNorm weight and bias must be given together");
   DLWP_REQUIRE(token_mlp_shape_ok(channels, hidden, nullptr), DLWP_ERR_UNSUPPORTED,
                "token MLP: channels %d (64 supported), hidden %d (multiple of 64, <= 256: weights must fit LDS)", channels, hidden);
   hipLaunchKernelGGL(tmlp::pack_kernel, dim3(64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w1_dev, w2_dev,
-                     reinterpret_cast<unsigned*>(packed_dev), channels, hidden);
+                     ln_gamma_dev, ln_beta_dev, b1_dev, reinterpret_cast<unsigned*>(packed_dev), channels, hidden);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
 
 extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev, const void* packed_dev,
                                       const float* b1_dev, const float* b2_dev, float* out_dev, int64_t tokens,
-                                      int32_t channels, int32_t hidden, void* stream) {
-  DLWP_REQUIRE(n_dev && packed_dev && b1_dev && out_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+                                      int32_t channels, int32_t hidden, float ln_eps, void* stream) {
+  const bool ln = ln_eps >= 0.f;
+  DLWP_REQUIRE(n_dev && packed_dev && (b1_dev || ln) && out_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(tokens > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
   size_t lds = 0;
   DLWP_REQUIRE(token_mlp_shape_ok(channels, hidden, &lds), DLWP_ERR_UNSUPPORTED,
@@ -298,7 +365,8 @@ extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev
   p.w2hm = p.w1hm + tmlp::n_w1hm(hidden, KS);
   p.w1l = p.w2hm + tmlp::n_w2hm(hidden, OT);
   p.w2l = p.w1l + tmlp::n_w1l(hidden, KS);
-  p.b1 = b1_dev;
+  p.b1 = ln ? reinterpret_cast<const float*>(p.w2l + tmlp::n_w2l(hidden, OT)) : b1_dev;
+  p.ln_eps = ln_eps;
   p.T = tokens;
   p.hid = hidden;
   p.trace = nullptr;
@@ -312,7 +380,8 @@ extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev
   }
   const long long npass = (tokens + 31) / 32;
   const unsigned grid = (unsigned)(npass < 8 * 256 ? (npass + 7) / 8 : 256);
-  auto kern = resid_dev ? tmlp::token_mlp_kernel<2, 4, true> : tmlp::token_mlp_kernel<2, 4, false>;
+  auto kern = ln ? (resid_dev ? tmlp::token_mlp_kernel<2, 4, true, true> : tmlp::token_mlp_kernel<2, 4, false, true>)
+                 : (resid_dev ? tmlp::token_mlp_kernel<2, 4, true, false> : tmlp::token_mlp_kernel<2, 4, false, false>);
   DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   DLWP_HIP_CHECK(hipGetLastError());

@@ -3,9 +3,11 @@ registered as `FourCastNet` like the reference registry (models/__init__.py:6). 
 kwargs (:215-234), state-dict names (`patch_embed.proj`, `pos_embed`, `blocks.{i}.{norm1,filter.{w1,b1,w2,b2},
 norm2,mlp.{fc1,fc2}}`, the unused `norm`, `head`) and forward signature.
 
-Per block the AFNO2D frequency-domain work (:87-121: four full-size zero buffers, slice-assigns, eight
-einsums, ReLU, softshrink) is ONE HIP kernel (`dlwp_afno2d_mix_f32`) between an rfft2 and an irfft2
-(currently torch.fft = rocFFT); LayerNorm / MLP / patch embedding / head run through torch on the GPU.
+Per block: LayerNorm 1 -> channels-first (HIP), hipFFT R2C, the AFNO2D frequency-domain work (:87-121: four
+full-size zero buffers, slice-assigns, eight einsums, ReLU, softshrink) as ONE in-place HIP kernel that also carries
+the "ortho" factors, hipFFT C2R, one merge kernel (+ bias path, first skip, back to tokens) and one token-MLP kernel
+(LayerNorm 2 -> fc1 -> GELU -> fc2 -> second skip).  Patch + position embedding is one kernel for 1x1 patches; the
+head is a torch GEMM.
 The rollout is device resident and does NOT reproduce the reference's crash on the second step
 (`.to()` on a list, :336-340) nor its per-step `.cpu()` (:359).
 """
@@ -70,10 +72,11 @@ class _Block(nn.Module):
         if self._mlp_fused is None:
             self._mlp_fused = ops.token_mlp_supported(x.shape[-1], m.fc1.out_features)
         if self._mlp_fused:
-            # fc1 -> GELU -> fc2 -> + second skip (:191-192) in one launch, in place on the merged sum
-            s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-            return ops.token_mlp(n, s, self._mlp_packed.get(m.fc1.weight, m.fc2.weight), m.fc1.bias, m.fc2.bias,
-                                 m.fc1.out_features, out=s)
+            # LayerNorm2 -> fc1 -> GELU -> fc2 -> + second skip (:191-192) in one launch, in place on the merged sum
+            # (norm2's affine part lives in the packed fc1 operands; the merge kernel only has to produce the sum)
+            s, _ = ops.afno_merge(f_cf, l_cf, x, None, None, self.norm2.eps, want_norm=False)
+            packed = self._mlp_packed.get(m.fc1.weight, m.fc2.weight, self.norm2.weight, self.norm2.bias, m.fc1.bias)
+            return ops.token_mlp(s, s, packed, None, m.fc2.bias, m.fc1.out_features, out=s, ln_eps=self.norm2.eps)
         # other widths: second skip folded into the fc2 GEMM -- the merge kernel stores sum + fc2.bias, addmm adds
         # onto it (beta = 1)
         s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, sum_bias=m.fc2.bias)

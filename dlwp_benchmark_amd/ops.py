@@ -248,20 +248,23 @@ def layernorm_nhwc_to_nchw(x: torch.Tensor, weight, bias, eps: float) -> torch.T
 
 
 def afno_merge(f_nchw: torch.Tensor, l_nchw: torch.Tensor, x_nhwc: torch.Tensor, weight, bias, eps: float,
-               sum_bias: Optional[torch.Tensor] = None):
-    """(f + l) transposed to token-major + x -> (sum [+ sum_bias], LayerNorm(sum)), both [B, H, W, C]."""
+               sum_bias: Optional[torch.Tensor] = None, want_norm: bool = True):
+    """(f + l) transposed to token-major + x -> (sum [+ sum_bias], LayerNorm(sum)), both [B, H, W, C].
+    want_norm=False returns (sum, None): for a consumer that normalises on the fly (token_mlp(ln_eps=...))."""
     for t, n in ((f_nchw, "f"), (l_nchw, "l"), (x_nhwc, "x")):
         _lib.require_cuda_tensor(t, n)
     f_nchw, l_nchw, x_nhwc = f_nchw.contiguous(), l_nchw.contiguous(), x_nhwc.contiguous()
     b, h, w, c = x_nhwc.shape
     s = torch.empty_like(x_nhwc)
-    n = torch.empty_like(x_nhwc)
+    n = torch.empty_like(x_nhwc) if want_norm else None
     lib = _lib.load()
     with torch.cuda.device(x_nhwc.device):
         _lib.check(lib.dlwp_afno_merge_f32(f_nchw.data_ptr(), l_nchw.data_ptr(), x_nhwc.data_ptr(),
-                                           weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                                           weight.contiguous().data_ptr() if want_norm else None,
+                                           bias.contiguous().data_ptr() if want_norm else None,
                                            sum_bias.contiguous().data_ptr() if sum_bias is not None else None,
-                                           s.data_ptr(), n.data_ptr(), b, h * w, c, float(eps), _lib.stream_ptr()),
+                                           s.data_ptr(), n.data_ptr() if want_norm else None, b, h * w, c, float(eps),
+                                           _lib.stream_ptr()),
                    "dlwp_afno_merge_f32")
     return s, n
 
@@ -297,34 +300,45 @@ def token_mlp_supported(channels: int, hidden: int) -> bool:
 
 class TokenMlpWeights:
     """fc1 / fc2 weights of a token MLP in the operand layout of dlwp_token_mlp_f32, re-packed on the device
-    whenever either parameter has been written to (optimizer step, load_state_dict, .to())."""
+    whenever a parameter has been written to (optimizer step, load_state_dict, .to()).  With `ln_weight` / `ln_bias`
+    (and `b1`) the affine part of the LayerNorm in front of fc1 is folded into the operands, for token_mlp(ln_eps=...)."""
 
     def __init__(self):
         self._key = None
         self._buf = None
 
-    def get(self, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
-        key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version, str(w1.device))
+    def get(self, w1: torch.Tensor, w2: torch.Tensor, ln_weight: Optional[torch.Tensor] = None,
+            ln_bias: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None) -> torch.Tensor:
+        extra = [t for t in (ln_weight, ln_bias, b1) if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in (w1, w2, *extra)) + (str(w1.device), ln_weight is not None)
         if key != self._key:
             hid, c = w1.shape
             if tuple(w2.shape) != (c, hid):
                 raise _lib.DlwpError(f"token MLP: fc2.weight {tuple(w2.shape)} does not match fc1.weight {tuple(w1.shape)}")
+            if (ln_weight is None) != (ln_bias is None):
+                raise _lib.DlwpError("token MLP: LayerNorm weight and bias must be given together")
             lib = _lib.load()
             nbytes = int(lib.dlwp_token_mlp_packed_bytes(c, hid))
             if nbytes == 0:
                 raise _lib.DlwpError(f"token MLP: unsupported shape channels={c} hidden={hid}")
             buf = torch.empty(nbytes // 4, dtype=torch.int32, device=w1.device)
+
+            def ptr(t):
+                return t.detach().contiguous().data_ptr() if t is not None else None
+
             with torch.cuda.device(w1.device):
-                _lib.check(lib.dlwp_token_mlp_pack_f32(w1.detach().contiguous().data_ptr(), w2.detach().contiguous().data_ptr(),
-                                                       c, hid, buf.data_ptr(), _lib.stream_ptr()), "dlwp_token_mlp_pack_f32")
+                _lib.check(lib.dlwp_token_mlp_pack_f32(ptr(w1), ptr(w2), ptr(ln_weight), ptr(ln_bias), ptr(b1), c, hid,
+                                                       buf.data_ptr(), _lib.stream_ptr()), "dlwp_token_mlp_pack_f32")
             self._key, self._buf = key, buf
         return self._buf
 
 
-def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tensor, b1: torch.Tensor,
-              b2: Optional[torch.Tensor], hidden: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tensor, b1: Optional[torch.Tensor],
+              b2: Optional[torch.Tensor], hidden: int, out: Optional[torch.Tensor] = None,
+              ln_eps: Optional[float] = None) -> torch.Tensor:
     """out = resid + b2 + fc2(gelu(fc1(n)))  over the last dimension (fourcastnet.py:41-57, :191-192), one launch.
-    `out` may be `resid` itself (in place)."""
+    With `ln_eps` the kernel first LayerNorms `n` (packed must carry the folded affine part and fc1 bias, see
+    TokenMlpWeights.get; b1 is then unused).  `out` may be `resid` / `n` itself (in place)."""
     _lib.require_cuda_tensor(n, "n")
     n = n.contiguous()
     c = n.shape[-1]
@@ -332,6 +346,8 @@ def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tens
         _lib.require_cuda_tensor(resid, "resid")
         if resid.shape != n.shape or not resid.is_contiguous():
             raise _lib.DlwpError("token MLP: resid must be contiguous and shaped like n")
+    if ln_eps is None and b1 is None:
+        raise _lib.DlwpError("token MLP: fc1 bias missing")
     if out is None:
         out = torch.empty_like(n)
     elif out.shape != n.shape or not out.is_contiguous():
@@ -339,8 +355,10 @@ def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tens
     lib = _lib.load()
     with torch.cuda.device(n.device):
         _lib.check(lib.dlwp_token_mlp_f32(n.data_ptr(), resid.data_ptr() if resid is not None else None, packed.data_ptr(),
-                                          b1.contiguous().data_ptr(), b2.contiguous().data_ptr() if b2 is not None else None,
-                                          out.data_ptr(), n.numel() // c, c, int(hidden), _lib.stream_ptr()),
+                                          b1.contiguous().data_ptr() if b1 is not None else None,
+                                          b2.contiguous().data_ptr() if b2 is not None else None,
+                                          out.data_ptr(), n.numel() // c, c, int(hidden),
+                                          float(ln_eps) if ln_eps is not None else -1.0, _lib.stream_ptr()),
                    "dlwp_token_mlp_f32")
     return out
 

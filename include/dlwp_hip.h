@@ -286,7 +286,9 @@ int32_t dlwp_layernorm_f32(const float* x_dev, const float* gamma_dev, const flo
  *       torch.fft.rfft2(dim=(1,2)) would otherwise do with a strided copy)
  *   dlwp_afno_merge_f32: sum = f + l + x  (irfft2 output + AFNO2D "+ bias" :127 + first skip :187),
  *       norm = LayerNorm2(sum) (:191); both token-major.  sum_bias_dev [C] or NULL is added to the STORED sum only:
- *       the host passes mlp.fc2.bias so that `mlp(norm) + sum` (:192) becomes one GEMM with beta = 1. */
+ *       the host passes mlp.fc2.bias so that `mlp(norm) + sum` (:192) becomes one GEMM with beta = 1.
+ *       norm_nhwc_dev NULL (then gamma / beta may be NULL too): only the sum is produced -- for callers whose next
+ *       kernel normalises on the fly (dlwp_token_mlp_f32 with ln_eps >= 0). */
 int32_t dlwp_layernorm_nhwc_to_nchw_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev,
                                         float* y_dev, int32_t batch, int64_t tokens, int32_t channels, float eps,
                                         void* stream);
@@ -311,15 +313,22 @@ int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_dev, const f
  * exact splits = fp32-GEMM accuracy).  channels == 64, hidden % 64 == 0, hidden <= 256 (weights are LDS resident);
  * anything else returns DLWP_ERR_UNSUPPORTED and the caller keeps its GEMM path.
  *   dlwp_token_mlp_packed_bytes: size of the packed-weight buffer (0 if the shape is unsupported)
- *   dlwp_token_mlp_pack_f32:     w1_dev [hidden][channels] (fc1.weight), w2_dev [channels][hidden] (fc2.weight) -> packed
- *   dlwp_token_mlp_f32:          resid_dev, b2_dev may be NULL; out_dev may alias resid_dev (each element is read
- *                                before it is written, by the same lane). */
+ *   dlwp_token_mlp_pack_f32:     w1_dev [hidden][channels] (fc1.weight), w2_dev [channels][hidden] (fc2.weight) -> packed.
+ *                                With ln_gamma_dev / ln_beta_dev [channels] (both or neither) the affine part of the
+ *                                LayerNorm in front of fc1 (`norm2`, :191) is folded in: W1 diag(gamma), and
+ *                                b1 + W1 beta (b1_dev [hidden] or NULL) is stored in the packed buffer.
+ *   dlwp_token_mlp_f32:          ln_eps < 0: n_dev is the fc1 input, b1_dev required.  ln_eps >= 0: n_dev is the
+ *                                UN-normalised token (normally the same buffer as resid_dev); the kernel normalises
+ *                                it (two-pass statistics over the channels) and takes b1 from a buffer packed WITH
+ *                                gamma / beta (b1_dev ignored).  resid_dev, b2_dev may be NULL; out_dev may alias
+ *                                resid_dev / n_dev (a wave reads all it needs of its 32 tokens before it writes). */
 size_t dlwp_token_mlp_packed_bytes(int32_t channels, int32_t hidden);
-int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, int32_t channels, int32_t hidden,
+int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
+                                const float* ln_beta_dev, const float* b1_dev, int32_t channels, int32_t hidden,
                                 void* packed_dev, void* stream);
 int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev, const void* packed_dev, const float* b1_dev,
                            const float* b2_dev, float* out_dev, int64_t tokens, int32_t channels, int32_t hidden,
-                           void* stream);
+                           float ln_eps, void* stream);
 
 /* On-device evaluation sums (reference scripts/evaluate.py:786-821 `compute_metrics` + the
  * de-normalisation of :281-296): out_dev, target_dev [B, K, C, H, W]; climatology_dev [K, C, H, W] or NULL;

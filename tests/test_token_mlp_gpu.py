@@ -46,6 +46,31 @@ def test_token_mlp_matches_fp64(tokens, hidden, use_resid, use_b2):
         assert torch.equal(out, got)
 
 
+@pytest.mark.parametrize("tokens", [4096, 777])
+def test_token_mlp_fused_layernorm_matches_fp64(tokens):
+    """LayerNorm(eps 1e-6) -> fc1 -> GELU -> fc2 -> + residual, in place on the residual, as the AFNO block calls it
+    (fourcastnet.py:191-192)."""
+    from dlwp_benchmark_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(4321 + tokens)
+    c, hidden, eps = 64, 256, 1e-6
+    s = (2.0 * torch.randn(tokens, c, generator=gen) + 0.5).to(dev)
+    gamma = (1.0 + 0.2 * torch.randn(c, generator=gen)).to(dev)
+    beta = (0.2 * torch.randn(c, generator=gen)).to(dev)
+    w1 = (torch.randn(hidden, c, generator=gen) / c ** 0.5).to(dev)
+    b1 = (0.3 * torch.randn(hidden, generator=gen)).to(dev)
+    w2 = (torch.randn(c, hidden, generator=gen) / hidden ** 0.5).to(dev)
+    b2 = (0.3 * torch.randn(c, generator=gen)).to(dev)
+    n64 = torch.nn.functional.layer_norm(s.double(), (c,), gamma.double(), beta.double(), eps)
+    want = _reference(n64, s, w1, b1, w2, b2)
+    packed = ops.TokenMlpWeights().get(w1, w2, gamma, beta, b1)
+    buf = s.clone()
+    got = ops.token_mlp(buf, buf, packed, None, b2, hidden, out=buf, ln_eps=eps)
+    assert got.data_ptr() == buf.data_ptr()
+    assert rel_l2(got, want) < 2e-6
+
+
 def test_token_mlp_repacks_after_weight_update():
     from dlwp_benchmark_amd import ops
 

@@ -9,8 +9,8 @@ for r in rows:
     launch, wave, st = r[0], r[1], r[2:]
     if launch != 1:
         continue
-    rt0, rt1 = st[254], st[255]
-    s = [x for x in st[:254] if x]
+    rt_entry, rt0, rt1 = st[253], st[254], st[255]
+    s = [x for x in st[:253] if x]
     ncyc = s[-1] - s[0]
     clk = ncyc / ((rt1 - rt0) * 10e-9) / 1e9 if rt1 > rt0 else float("nan")
     per_pass = 2 + 8   # start, operands ready, 8 units
@@ -21,7 +21,7 @@ for r in rows:
         load.append(b[1] - b[0])
         units.append([b[i + 1] - b[i] for i in range(1, 9)])
     flat = [u for us in units for u in us]
-    print(f"wave {wave}: {npass} passes, {ncyc} cycles, clock {clk:.2f} GHz; operand phase avg {sum(load) / len(load):.0f} "
+    print(f"wave {wave}: staging {(rt0 - rt_entry) * 0.01:.1f} us, loop {(rt1 - rt0) * 0.01:.1f} us; {npass} passes, {ncyc} cycles, clock {clk:.2f} GHz; operand phase avg {sum(load) / len(load):.0f} "
           f"(max {max(load)}); unit avg {sum(flat) / len(flat):.0f} min {min(flat)} max {max(flat)}; "
           f"last unit of a pass (incl. stores + next loop top) avg {sum(u[-1] for u in units) / len(units):.0f}")
     if wave in (0, 4):
