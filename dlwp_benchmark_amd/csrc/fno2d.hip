@@ -20,6 +20,17 @@
 //   fused kernel each (hidden 256-wide activation never leaves registers).
 #include "common.hpp"
 
+// GELU form per phase of the fused step kernel (A/B switch: -DDLWP_GELU8_LIFT=gelu_erf8_fma etc.)
+#ifndef DLWP_GELU8_LIFT
+#define DLWP_GELU8_LIFT gelu_erf8
+#endif
+#ifndef DLWP_GELU8_PROJ
+#define DLWP_GELU8_PROJ gelu_erf8
+#endif
+#ifndef DLWP_GELU8_TRUNK
+#define DLWP_GELU8_TRUNK gelu_erf8
+#endif
+
 namespace dlwp {
 namespace fno {
 
@@ -352,10 +363,10 @@ __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const
     load_wa(u_m);
     unit_valu_fc1(u_v, qv);
     unit_mfma(bgm, qm, I0{});
-    gelu_erf8(a1[0][0], a1[0][1]);
+    DLWP_GELU8_LIFT(a1[0][0], a1[0][1]);
     __builtin_amdgcn_sched_barrier(0);
     unit_mfma(bgm, qm, I1{});
-    gelu_erf8(a1[1][0], a1[1][1]);
+    DLWP_GELU8_LIFT(a1[1][0], a1[1][1]);
     __builtin_amdgcn_sched_barrier(0);
     unit_mfma(bgm, qm, I2{});
     unit_split(bgv);
@@ -363,8 +374,8 @@ __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const
   };
   // prologue: unit 0 (tile pair 0, chains 0-1) on the fp32 lanes only
   unit_valu_fc1(0, I0{});
-  gelu_erf8(a1[0][0], a1[0][1]);
-  gelu_erf8(a1[1][0], a1[1][1]);
+  DLWP_GELU8_LIFT(a1[0][0], a1[0][1]);
+  DLWP_GELU8_LIFT(a1[1][0], a1[1][1]);
   unit_split(bg0);
   for (int u = 0; u < npair; ++u) {
     trip(u, u, bg0, bg1, I0{}, I1{});                            // MFMA unit (u,0) | VALU unit (u,1)
@@ -598,8 +609,8 @@ __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x
   fc1(ntile > 1 ? 1 : 0, a_nxt);
 #pragma unroll
   for (int q = 0; q < 4; ++q) g_prev[q] = a_cur[q];
-  gelu_erf8(g_prev[0], g_prev[1]);
-  gelu_erf8(g_prev[2], g_prev[3]);
+  DLWP_GELU8_PROJ(g_prev[0], g_prev[1]);
+  DLWP_GELU8_PROJ(g_prev[2], g_prev[3]);
 #pragma unroll
   for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
   // LDS operands are fetched ONE TILE AHEAD of the MFMAs / FMAs that consume them (the matrix instructions at the top
@@ -631,7 +642,7 @@ __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x
       a_nxt[2 * i + 1] = mfma_bf16x6(wa, bx[2 * i + 1], bb);
       g_new[2 * i] = a_cur[2 * i];
       g_new[2 * i + 1] = a_cur[2 * i + 1];
-      gelu_erf8(g_new[2 * i], g_new[2 * i + 1]);
+      DLWP_GELU8_PROJ(g_new[2 * i], g_new[2 * i + 1]);
 #pragma unroll
       for (int co = 0; co < CO; ++co)
 #pragma unroll
@@ -1788,8 +1799,8 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
       // neuralop FNOBlocks.forward_with_postactivation: GELU after every layer but the last
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot) {
-        gelu_erf8(vv[ot][0], vv[ot][1]);
-        gelu_erf8(vv[ot][2], vv[ot][3]);
+        DLWP_GELU8_TRUNK(vv[ot][0], vv[ot][1]);
+        DLWP_GELU8_TRUNK(vv[ot][2], vv[ot][3]);
       }
       DLWP_STAMP();
 #pragma unroll

@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdlwp_hip.so")
+LIB_PATH = os.environ.get("DLWP_HIP_LIB") or os.path.join(_HERE, "libdlwp_hip.so")   # override: A/B builds of the same ABI
 
 c_float_p = POINTER(c_float)
 c_int32_p = POINTER(c_int32)
