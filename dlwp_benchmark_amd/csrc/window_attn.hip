@@ -86,20 +86,29 @@ __device__ __forceinline__ int pack_info(const Coord& c) {
 // DT = head_dim / 4, DB = ceil(head_dim / 16) (16-row blocks of O^T), SUB = 16-query sub-tiles per wave.
 // Block = 4 waves = 64*SUB queries of one (batch, window, head); keys stream through LDS in tiles of 32.
 //
-// BF16 = false: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32 products; the parity path).
-// BF16 = true : Q, K, V and P rounded to bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation and fp32
-//               softmax statistics; head_dim is one (<= 32) or two k-steps deep, so a 32-key x 16-query
-//               tile costs 2-4 + DB matrix instructions instead of 2*DT + 8*DB.
+// PREC = 0: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32 products; cross-check, dlwp_set_fp32_mfma(1)).
+// PREC = 1: Q, K, V and P rounded to bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation and fp32
+//           softmax statistics; head_dim is one (<= 32) or two k-steps deep, so a 32-key x 16-query
+//           tile costs 2-4 + DB matrix instructions instead of 2*DT + 8*DB.
+// PREC = 2: "bf16x6", the default of dlwp_window_attn_f32 (the parity path): Q, K, V and P split EXACTLY into three
+//           bf16 parts each (common.hpp), six cross products per contraction accumulated in fp32 -- fp32-GEMM
+//           accuracy on the bf16 matrix pipe: 6 x 16 cycles per 32-deep k-step instead of 8 x 32 for the same
+//           contraction on fp32 MFMA, and the bf16 pipe leaves the fp32 lanes to the softmax.
 // LON4: the window's fastest axis is a multiple of 4, so the 4 keys a lane owns in a 16-key block
 //       (rows 4g..4g+3 of the accumulator) are consecutive along longitude: ONE bias index per 4 scores.
 // All score arithmetic is in the log2 domain (q scale, bias table and mask are pre-multiplied by
 // log2 e) so the softmax exponentials are bare v_exp_f32.
-template <int DT, int DB, int SUB, bool BF16, bool LON4, bool MASK>
+__device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};   // bf16x6 terms, smallest first: (A part, B part) =
+__device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};   // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+
+template <int DT, int DB, int SUB, int PREC, bool LON4, bool MASK>
 __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const float* __restrict__ qkv,
                                                           const float* __restrict__ qkv_bias,
                                                           const float* __restrict__ table,
                                                           float* __restrict__ out, long long L) {
   extern __shared__ __align__(16) float smem[];
+  constexpr bool BF16 = PREC != 0;
+  constexpr int NP = PREC == 2 ? 3 : 1;        // bf16 parts per operand
   constexpr int KT = 32;                       // keys per tile
   constexpr int LDK = 4 * DT + 2;              // fp32 K tile row stride (floats)
   constexpr int LDV = 16 * DB + 4;             // fp32 V tile row stride
@@ -123,9 +132,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
   float* s_kv = s_tab + ((D.table_rows + 3) & ~3);       // K / V tiles (layout depends on BF16)
   float* s_k = s_kv;                                     // fp32: [KT][LDK]
   float* s_v = s_k + KT * LDK;                           // fp32: [KT][LDV]
-  unsigned short* s_kb = reinterpret_cast<unsigned short*>(s_kv);   // bf16: [KT][LDKB]
-  unsigned short* s_vb = s_kb + KT * LDKB;                          // bf16: [16*DB][LDVB]  (V transposed)
-  constexpr int KV_FLOATS = BF16 ? (KT * LDKB + 16 * DB * LDVB + 1) / 2 : KT * (LDK + LDV);
+  unsigned short* s_kb = reinterpret_cast<unsigned short*>(s_kv);   // bf16: [NP][KT][LDKB]
+  unsigned short* s_vb = s_kb + NP * KT * LDKB;                     // bf16: [NP][16*DB][LDVB]  (V transposed)
+  constexpr int KV_FLOATS = BF16 ? (NP * (KT * LDKB + 16 * DB * LDVB) + 1) / 2 : KT * (LDK + LDV);
   int* s_info = reinterpret_cast<int*>(s_kv + ((KV_FLOATS + 3) & ~3));  // [KT] packed key coords, -1 beyond N
   constexpr int EPI_FLOATS = 64 * SUB * (16 * DB + 1);
   constexpr int TILE_FLOATS = ((KV_FLOATS + 3) & ~3) + KT;
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
 
   for (int n = tid; n < N; n += 256) {
     const Coord c = token_coord(D, ipl, ilat, ilon, n);
-    s_msrc[n] = (int)c.src;
+    s_msrc[n] = c.src >= 0 ? (int)c.src * 3 * C : -1;   // ELEMENT offset of the token's qkv row (fits 31 bits, checked on the host)
     s_minfo[n] = pack_info(c);
   }
   __syncthreads();
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
   const int q_base = blockIdx.x * (64 * SUB) + wave * (16 * SUB);
   const float qscale = D.scale * LOG2E;
   float qreg[BF16 ? 1 : SUB][BF16 ? 1 : DT];      // fp32 path: B[k = g][col j] per k-step
-  u32x4 qb[BF16 ? SUB : 1][BF16 ? DK : 1];         // bf16 path: 8 consecutive head dims per k-step
+  u32x4 qb[BF16 ? SUB : 1][BF16 ? DK : 1][NP];     // bf16 paths: 8 consecutive head dims per k-step (x parts)
   int qinfo[SUB];
 #pragma unroll
   for (int sub = 0; sub < SUB; ++sub) {
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
     const bool live = qn < N;
     const int qsrc = live ? s_msrc[qn] : -1;
     qinfo[sub] = live ? s_minfo[qn] : 0;
-    const float* src = (live && qsrc >= 0) ? qkv_b + (long long)qsrc * 3 * C + head * d : qkv_bias + head * d;
+    const float* src = (live && qsrc >= 0) ? qkv_b + qsrc + head * d : qkv_bias + head * d;
     if constexpr (!BF16) {
 #pragma unroll
       for (int s = 0; s < DT; ++s) qreg[sub][s] = live ? src[4 * s + g] * qscale : 0.f;
@@ -172,7 +181,15 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
           const int e = 32 * ks + 8 * g + 2 * i;
           const float v0 = (live && e < d) ? src[e] * qscale : 0.f;
           const float v1 = (live && e + 1 < d) ? src[e + 1] * qscale : 0.f;
-          qb[sub][ks][i] = cvt_pk_bf16(v0, v1);
+          if constexpr (PREC == 2) {
+            unsigned hh, mm, ll;
+            split3_pair(v0, v1, hh, mm, ll);
+            qb[sub][ks][0][i] = hh;
+            qb[sub][ks][1][i] = mm;
+            qb[sub][ks][2][i] = ll;
+          } else {
+            qb[sub][ks][0][i] = cvt_pk_bf16(v0, v1);
+          }
         }
     }
   }
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
         if (i < KT * 4 * DT && kn < N) {
           const int ksrc = s_msrc[kn];
           pinfo[it] = s_minfo[kn];
-          const float* src = ksrc >= 0 ? qkv_b + (long long)ksrc * 3 * C + head * d : qkv_bias + head * d;
+          const float* src = ksrc >= 0 ? qkv_b + ksrc + head * d : qkv_bias + head * d;
           pk0[it] = src[C + e];
           pv0[it] = src[2 * C + e];
         }
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
         if (i < KT * EP && kn < N) {
           const int ksrc = s_msrc[kn];
           pinfo[it] = s_minfo[kn];
-          const float* src = ksrc >= 0 ? qkv_b + (long long)ksrc * 3 * C + head * d : qkv_bias + head * d;
+          const float* src = ksrc >= 0 ? qkv_b + ksrc + head * d : qkv_bias + head * d;
           if (e < d) { pk0[it] = src[C + e]; pv0[it] = src[2 * C + e]; }
           if (e + 1 < d) { pk1[it] = src[C + e + 1]; pv1[it] = src[2 * C + e + 1]; }
         }
@@ -242,15 +259,26 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
         // key): 4-way bank conflicts on sub-dword writes, 13 % of the CU's cycles (profiles/
         // r01_f_swin_attention_sq_counters.txt).  Now the lane pair (2m, 2m+1) = keys (2kp, 2kp+1) swaps halves and
         // each lane writes ONE dword: row e for the even lane, row e+1 for the odd one.
-        const unsigned vp = cvt_pk_bf16(pv0[it], pv1[it]);
-        const unsigned vq = (unsigned)__shfl_xor((int)vp, 1);
+        unsigned vp[NP], kw[NP], vq[NP];
+        if constexpr (PREC == 2) {
+          split3_pair(pv0[it], pv1[it], vp[0], vp[1], vp[2]);
+          split3_pair(pk0[it], pk1[it], kw[0], kw[1], kw[2]);
+        } else {
+          vp[0] = cvt_pk_bf16(pv0[it], pv1[it]);
+          kw[0] = cvt_pk_bf16(pk0[it], pk1[it]);
+        }
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) vq[pp] = (unsigned)__shfl_xor((int)vp[pp], 1);
         if (i < KT * EP) {
           const int kbit = i & 1, kp = i / (2 * EP), key = 2 * kp + kbit, e = 2 * ((i >> 1) % EP);
           if (e == 0) s_info[key] = pinfo[it];
-          *reinterpret_cast<unsigned*>(s_kb + key * LDKB + e) = cvt_pk_bf16(pk0[it], pk1[it]);
-          if (e < 16 * DB) {
-            const unsigned word = kbit ? ((vq >> 16) | (vp & 0xFFFF0000u)) : ((vp & 0xFFFFu) | (vq << 16));
-            *reinterpret_cast<unsigned*>(s_vb + (e + kbit) * LDVB + 2 * kp) = word;
+#pragma unroll
+          for (int pp = 0; pp < NP; ++pp) {
+            *reinterpret_cast<unsigned*>(s_kb + (pp * KT + key) * LDKB + e) = kw[pp];
+            if (e < 16 * DB) {
+              const unsigned word = kbit ? ((vq[pp] >> 16) | (vp[pp] & 0xFFFF0000u)) : ((vp[pp] & 0xFFFFu) | (vq[pp] << 16));
+              *reinterpret_cast<unsigned*>(s_vb + (pp * 16 * DB + e + kbit) * LDVB + 2 * kp) = word;
+            }
           }
         }
       }
@@ -276,17 +304,31 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
     for (int sub = 0; sub < SUB; ++sub) {
       // ---- S^T[key][query] for the two 16-key blocks of the tile
       f32x4 sc[2];
+      sc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      sc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (!BF16) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        sc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (!BF16) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int s = 0; s < DT; ++s) sc[kb] = mfma16x16x4(s_k[(kb * 16 + j) * LDK + 4 * s + g], qreg[sub][s], sc[kb]);
-        } else {
+      } else {
 #pragma unroll
-          for (int ks = 0; ks < DK; ++ks) {
-            const u32x4 ka = *reinterpret_cast<const u32x4*>(s_kb + (kb * 16 + j) * LDKB + 32 * ks + 8 * g);
-            sc[kb] = mfma16x16x32_bf16(ka, qb[sub][ks], sc[kb]);
+        for (int ks = 0; ks < DK; ++ks) {
+          u32x4 ka[2][NP];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp)
+              ka[kb][pp] = *reinterpret_cast<const u32x4*>(s_kb + (pp * KT + kb * 16 + j) * LDKB + 32 * ks + 8 * g);
+          if constexpr (PREC == 2) {
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+              for (int kb = 0; kb < 2; ++kb)
+                sc[kb] = mfma16x16x32_bf16(ka[kb][kPA[term]], qb[sub][ks][kPB[term]], sc[kb]);
+          } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sc[kb] = mfma16x16x32_bf16(ka[kb][0], qb[sub][ks][0], sc[kb]);
           }
         }
       }
@@ -344,8 +386,12 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
           psum += pexp;
         }
       l_run[sub] = l_run[sub] * alpha + psum;
+      // the accumulators live in AGPRs: rescaling them costs a read + multiply + write per register.  Once the running
+      // maxima of the wave's 16 queries have settled (most tiles after the first few) alpha is exactly 1 everywhere.
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) oacc[sub][db] *= alpha;
+        for (int db = 0; db < DB; ++db) oacc[sub][db] *= alpha;
+      }
       // ---- O^T[dim][query] += V^T[dim][key] P^T[key][query]; the keys a lane holds (accumulator rows
       // 4g + r of the two blocks) are exactly the k-slots it supplies: no lane movement
       if constexpr (!BF16) {
@@ -358,15 +404,39 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
               oacc[sub][db] = mfma16x16x4(s_v[(kb * 16 + 4 * g + r) * LDV + 16 * db + j], sc[kb][r], oacc[sub][db]);
       } else {
         // k-slot jj of lane group g: jj < 4 -> key 4g + jj, jj >= 4 -> key 16 + 4g + (jj - 4)
-        const u32x4 pb = {cvt_pk_bf16(sc[0][0], sc[0][1]), cvt_pk_bf16(sc[0][2], sc[0][3]),
-                          cvt_pk_bf16(sc[1][0], sc[1][1]), cvt_pk_bf16(sc[1][2], sc[1][3])};
+        u32x4 pb[NP];
+        if constexpr (PREC == 2) {
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const unsigned short* vr = s_vb + (16 * db + j) * LDVB + 4 * g;
-          const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-          const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
-          const u32x4 va = {lo.x, lo.y, hi.x, hi.y};
-          oacc[sub][db] = mfma16x16x32_bf16(va, pb, oacc[sub][db]);
+          for (int i = 0; i < 4; ++i) {
+            unsigned hh, mm, ll;
+            split3_pair(sc[i >> 1][2 * (i & 1)], sc[i >> 1][2 * (i & 1) + 1], hh, mm, ll);
+            pb[0][i] = hh;
+            pb[1][i] = mm;
+            pb[2][i] = ll;
+          }
+        } else {
+          pb[0] = u32x4{cvt_pk_bf16(sc[0][0], sc[0][1]), cvt_pk_bf16(sc[0][2], sc[0][3]),
+                        cvt_pk_bf16(sc[1][0], sc[1][1]), cvt_pk_bf16(sc[1][2], sc[1][3])};
+        }
+        u32x4 va[DB][NP];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int pp = 0; pp < NP; ++pp) {
+            const unsigned short* vr = s_vb + (pp * 16 * DB + 16 * db + j) * LDVB + 4 * g;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+            const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+            va[db][pp] = u32x4{lo.x, lo.y, hi.x, hi.y};
+          }
+        if constexpr (PREC == 2) {
+#pragma unroll
+          for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+              oacc[sub][db] = mfma16x16x32_bf16(va[db][kPA[term]], pb[kPB[term]], oacc[sub][db]);
+        } else {
+#pragma unroll
+          for (int db = 0; db < DB; ++db) oacc[sub][db] = mfma16x16x32_bf16(va[db][0], pb[0], oacc[sub][db]);
         }
       }
     }
@@ -403,21 +473,24 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
 }  // namespace wattn
 }  // namespace dlwp
 
+namespace dlwp { namespace fno { bool use_bf16x6_layer(); } }   // fno2d.hip: the process-wide fp32-MFMA / bf16x6 switch
+
 using namespace dlwp;
 using namespace dlwp::wattn;
 
-template <int DT, int DB, int SUB, bool BF16, bool LON4>
+template <int DT, int DB, int SUB, int PREC, bool LON4>
 static int32_t launch_wattn_k(const Desc& D, const float* qkv, const float* qkv_bias, const float* table, float* out,
                               int batch, long long L, hipStream_t s) {
   const int nwin = D.npl * D.nlat * D.nlon;
   constexpr int KT = 32, LDK = 4 * DT + 2, LDV = 16 * DB + 4, DK = (4 * DT + 31) / 32, LDKB = 32 * DK + 8, LDVB = KT + 8;
-  constexpr int KV_FLOATS = BF16 ? (KT * LDKB + 16 * DB * LDVB + 1) / 2 : KT * (LDK + LDV);
+  constexpr int NP = PREC == 2 ? 3 : 1;
+  constexpr int KV_FLOATS = PREC ? (NP * (KT * LDKB + 16 * DB * LDVB) + 1) / 2 : KT * (LDK + LDV);
   const size_t tab = (size_t)((D.table_rows + 3) & ~3);
   const size_t tile_f = (size_t)((KV_FLOATS + 3) & ~3) + KT, epi_f = (size_t)64 * SUB * (16 * DB + 1);
   const size_t lds = (tab + (((tile_f > epi_f ? tile_f : epi_f) + 3) & ~(size_t)3) + 2 * (size_t)((D.N + 3) & ~3)) * 4;
   DLWP_REQUIRE(lds <= 160 * 1024, DLWP_ERR_UNSUPPORTED, "window attention needs %zu bytes of LDS (bias table too large)", lds);
   const dim3 grid((D.N + 64 * SUB - 1) / (64 * SUB), D.heads, batch * nwin);
-  auto kern = D.use_mask ? window_attn_kernel<DT, DB, SUB, BF16, LON4, true> : window_attn_kernel<DT, DB, SUB, BF16, LON4, false>;
+  auto kern = D.use_mask ? window_attn_kernel<DT, DB, SUB, PREC, LON4, true> : window_attn_kernel<DT, DB, SUB, PREC, LON4, false>;
   if (lds > 48 * 1024)
     DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, D, qkv, qkv_bias, table, out, L);
@@ -427,16 +500,18 @@ static int32_t launch_wattn_k(const Desc& D, const float* qkv, const float* qkv_
 
 template <int DT, int DB>
 static int32_t launch_wattn(const Desc& D, const float* qkv, const float* qkv_bias, const float* table, float* out,
-                            int batch, long long L, hipStream_t s, bool bf16) {
+                            int batch, long long L, hipStream_t s, int prec) {
   // queries per workgroup = 64 * SUB.  Large windows: 128; small windows: the whole window in one
   // workgroup when it fits 256 queries, so the bias column / token map staging is paid once per
   // (window, head) instead of once per 64 queries (Pangu: N = 144 -> SUB = 3)
-  const int sub = D.N >= 512 ? 2 : (D.N <= 64 ? 1 : (D.N <= 128 ? 2 : (D.N <= 192 ? 3 : 4)));
+  int sub = D.N >= 512 ? 2 : (D.N <= 64 ? 1 : (D.N <= 128 ? 2 : (D.N <= 192 ? 3 : 4)));
+  static const char* sub_env = getenv("DLWP_WATTN_SUB");   // A/B: 16-query sub-tiles per wave for large windows
+  if (sub_env && D.N >= 512 && atoi(sub_env) >= 1 && atoi(sub_env) <= 4) sub = atoi(sub_env);
   const bool lon4 = (D.wlon % 4) == 0;
 #define DLWP_WA2(SUB_, BF_) \
   do { if (lon4) return launch_wattn_k<DT, DB, SUB_, BF_, true>(D, qkv, qkv_bias, table, out, batch, L, s); \
        else return launch_wattn_k<DT, DB, SUB_, BF_, false>(D, qkv, qkv_bias, table, out, batch, L, s); } while (0)
-#define DLWP_WA(SUB_) do { if (bf16) DLWP_WA2(SUB_, true); else DLWP_WA2(SUB_, false); } while (0)
+#define DLWP_WA(SUB_) do { if (prec == 2) DLWP_WA2(SUB_, 2); else if (prec == 1) DLWP_WA2(SUB_, 1); else DLWP_WA2(SUB_, 0); } while (0)
   switch (sub) {
     case 1: DLWP_WA(1);
     case 2: DLWP_WA(2);
@@ -448,7 +523,7 @@ static int32_t launch_wattn(const Desc& D, const float* qkv, const float* qkv_bi
 }
 
 static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias, const float* table,
-                                float* out, int32_t batch, void* stream, bool bf16) {
+                                float* out, int32_t batch, void* stream, int prec) {
   DLWP_REQUIRE(u && qkv && table && out, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0, DLWP_ERR_INVALID_ARGUMENT, "batch must be positive");
   Desc D;
@@ -491,10 +566,11 @@ static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, cons
                "head_dim %d: kernels are instantiated for 8, 16, 24, 32, 48, 64", D.d);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long L = (long long)D.pl * D.lat * D.lon;
+  DLWP_REQUIRE(L * 3 * D.C < (1ll << 31), DLWP_ERR_UNSUPPORTED, "window attention: %lld tokens x 3 x %d channels overflow the 31-bit token offsets", L, D.C);
   const float* qb = qkv_bias ? qkv_bias : qkv;  // never dereferenced when nothing is padded
   switch (D.d / 4) {
 #define DLWP_CASE(DT_) \
-  case DT_: return launch_wattn<DT_, (4 * DT_ + 15) / 16>(D, qkv, qb, table, out, batch, L, s, bf16);
+  case DT_: return launch_wattn<DT_, (4 * DT_ + 15) / 16>(D, qkv, qb, table, out, batch, L, s, prec);
     DLWP_CASE(2) DLWP_CASE(4) DLWP_CASE(6) DLWP_CASE(8) DLWP_CASE(12) DLWP_CASE(16)
 #undef DLWP_CASE
     default: break;
@@ -504,10 +580,12 @@ static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, cons
 
 extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
                                         const float* table, float* out, int32_t batch, void* stream) {
-  return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, false);
+  // fp32-accurate either way: bf16x6 on the bf16 matrix pipe by default, the plain fp32-MFMA kernel under
+  // dlwp_set_fp32_mfma(1) / DLWP_FP32_MFMA=1 (cross-check, like the FNO kernels)
+  return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, dlwp::fno::use_bf16x6_layer() ? 2 : 0);
 }
 
 extern "C" int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
                                          const float* table, float* out, int32_t batch, void* stream) {
-  return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, true);
+  return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, 1);
 }

@@ -195,6 +195,10 @@ typedef struct dlwp_wattn_desc {
   float scale;            /* qk scale (head_dim ** -0.5 unless overridden)                     */
 } dlwp_wattn_desc;
 
+/* fp32-accurate (the parity path).  Both contractions run on the bf16 matrix pipe as exact three-way bf16 splits of
+ * Q, K, V and P with six cross products each ("bf16x6": fp32-GEMM accuracy, 1e-5 per-step parity with the reference);
+ * dlwp_set_fp32_mfma(1) / DLWP_FP32_MFMA=1 selects the plain v_mfma_f32_16x16x4_f32 kernel instead (cross-check).
+ * tokens * 3 * heads * head_dim must stay below 2^31 (token offsets are 32-bit). */
 int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* desc, const float* qkv_dev,
                              const float* qkv_bias_dev, const float* table_dev, float* out_dev,
                              int32_t batch, void* stream);
