@@ -129,18 +129,27 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
   const int d = D.d, C = D.C, N = D.N;
 
   float* s_tab = smem;                                   // [table_rows] bias column * log2 e
-  float* s_kv = s_tab + ((D.table_rows + 3) & ~3);       // K / V tiles (layout depends on BF16)
-  float* s_k = s_kv;                                     // fp32: [KT][LDK]
-  float* s_v = s_k + KT * LDK;                           // fp32: [KT][LDV]
-  unsigned short* s_kb = reinterpret_cast<unsigned short*>(s_kv);   // bf16: [NP][KT][LDKB]
-  unsigned short* s_vb = s_kb + NP * KT * LDKB;                     // bf16: [NP][16*DB][LDVB]  (V transposed)
+  float* s_kv = s_tab + ((D.table_rows + 3) & ~3);       // TWO K / V tile buffers (layout depends on BF16)
+  float* s_k;                                            // fp32: [KT][LDK]
+  float* s_v;                                            // fp32: [KT][LDV]
+  unsigned short* s_kb;                                  // bf16: [NP][KT][LDKB]
+  unsigned short* s_vb;                                  // bf16: [NP][16*DB][LDVB]  (V transposed)
+  int* s_info;                                           // [KT] packed key coords, -1 beyond N
   constexpr int KV_FLOATS = BF16 ? (NP * (KT * LDKB + 16 * DB * LDVB) + 1) / 2 : KT * (LDK + LDV);
-  int* s_info = reinterpret_cast<int*>(s_kv + ((KV_FLOATS + 3) & ~3));  // [KT] packed key coords, -1 beyond N
   constexpr int EPI_FLOATS = 64 * SUB * (16 * DB + 1);
   constexpr int TILE_FLOATS = ((KV_FLOATS + 3) & ~3) + KT;
+  auto set_buf = [&](int bsel) {   // point the tile views at buffer bsel
+    float* base = s_kv + bsel * TILE_FLOATS;
+    s_k = base;
+    s_v = s_k + KT * LDK;
+    s_kb = reinterpret_cast<unsigned short*>(base);
+    s_vb = s_kb + NP * KT * LDKB;
+    s_info = reinterpret_cast<int*>(base + ((KV_FLOATS + 3) & ~3));
+  };
+  set_buf(0);
   // window token map, computed once per workgroup: source token (or -1 = zero-padded) and packed
   // coordinates / region of every in-window position (token_coord is ~10 integer divisions)
-  int* s_msrc = reinterpret_cast<int*>(s_kv + (((TILE_FLOATS > EPI_FLOATS ? TILE_FLOATS : EPI_FLOATS) + 3) & ~3));  // [N]
+  int* s_msrc = reinterpret_cast<int*>(s_kv + (((2 * TILE_FLOATS > EPI_FLOATS ? 2 * TILE_FLOATS : EPI_FLOATS) + 3) & ~3));  // [N]
   int* s_minfo = s_msrc + ((N + 3) & ~3);                                                                        // [N]
 
   {
@@ -285,20 +294,25 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
     }
   };
   if constexpr (!BF16) {
-    if (16 * DB > 4 * DT) {   // pad columns of V (head_dim not a multiple of 16): zero once
-      for (int i = tid; i < KT * (16 * DB - 4 * DT); i += 256) {
-        const int key = i / (16 * DB - 4 * DT), e = 4 * DT + i % (16 * DB - 4 * DT);
-        s_v[key * LDV + e] = 0.f;
+    if (16 * DB > 4 * DT) {   // pad columns of V (head_dim not a multiple of 16): zero once, in both buffers
+      for (int i = tid; i < 2 * KT * (16 * DB - 4 * DT); i += 256) {
+        const int bsel = i / (KT * (16 * DB - 4 * DT)), ii = i % (KT * (16 * DB - 4 * DT));
+        const int key = ii / (16 * DB - 4 * DT), e = 4 * DT + ii % (16 * DB - 4 * DT);
+        (s_kv + bsel * TILE_FLOATS + KT * LDK)[key * LDV + e] = 0.f;
       }
     }
   }
+  // Two tile buffers, ONE barrier per tile: tile kt+1 is written (from the registers stage_load filled during tile kt-1's
+  // compute) right after this wave's compute on tile kt, into the buffer every wave finished reading before the barrier
+  // that ended iteration kt-1.  (The single-buffer form needed a second barrier per tile -- "everyone done reading" --
+  // at which the 4 waves of the workgroup waited for the slowest one twice per 32 keys.)
   stage_load(0);
+  stage_write();
+  __syncthreads();
+  if (ntile > 1) stage_load(1);
   for (int kt = 0; kt < ntile; ++kt) {
     const bool tail = (kt == ntile - 1) && (N % KT != 0);
-    __syncthreads();          // everyone is done reading the previous tile
-    stage_write();
-    __syncthreads();
-    if (kt + 1 < ntile) stage_load(kt + 1);
+    set_buf(kt & 1);
 
 #pragma unroll
     for (int sub = 0; sub < SUB; ++sub) {
@@ -440,10 +454,15 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
         }
       }
     }
+    if (kt + 1 < ntile) {
+      set_buf((kt + 1) & 1);
+      stage_write();
+      if (kt + 2 < ntile) stage_load(kt + 2);
+    }
+    __syncthreads();
   }
 
   // ---- epilogue: normalise, transpose through LDS (reusing the K/V tile area), store whole rows
-  __syncthreads();
   float* s_o = s_kv;  // [64*SUB queries][16*DB + 1]
   constexpr int LDO = 16 * DB + 1;
 #pragma unroll
@@ -486,7 +505,7 @@ static int32_t launch_wattn_k(const Desc& D, const float* qkv, const float* qkv_
   constexpr int NP = PREC == 2 ? 3 : 1;
   constexpr int KV_FLOATS = PREC ? (NP * (KT * LDKB + 16 * DB * LDVB) + 1) / 2 : KT * (LDK + LDV);
   const size_t tab = (size_t)((D.table_rows + 3) & ~3);
-  const size_t tile_f = (size_t)((KV_FLOATS + 3) & ~3) + KT, epi_f = (size_t)64 * SUB * (16 * DB + 1);
+  const size_t tile_f = 2 * ((size_t)((KV_FLOATS + 3) & ~3) + KT), epi_f = (size_t)64 * SUB * (16 * DB + 1);
   const size_t lds = (tab + (((tile_f > epi_f ? tile_f : epi_f) + 3) & ~(size_t)3) + 2 * (size_t)((D.N + 3) & ~3)) * 4;
   DLWP_REQUIRE(lds <= 160 * 1024, DLWP_ERR_UNSUPPORTED, "window attention needs %zu bytes of LDS (bias table too large)", lds);
   const dim3 grid((D.N + 64 * SUB - 1) / (64 * SUB), D.heads, batch * nwin);
