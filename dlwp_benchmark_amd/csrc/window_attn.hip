@@ -86,14 +86,15 @@ __device__ __forceinline__ int pack_info(const Coord& c) {
 // DT = head_dim / 4, DB = ceil(head_dim / 16) (16-row blocks of O^T), SUB = 16-query sub-tiles per wave.
 // Block = 4 waves = 64*SUB queries of one (batch, window, head); keys stream through LDS in tiles of 32.
 //
-// PREC = 0: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32 products; cross-check, dlwp_set_fp32_mfma(1)).
+// PREC = 0: fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32 products; dlwp_window_attn_f32 for windows >= 512 tokens).
 // PREC = 1: Q, K, V and P rounded to bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation and fp32
 //           softmax statistics; head_dim is one (<= 32) or two k-steps deep, so a 32-key x 16-query
 //           tile costs 2-4 + DB matrix instructions instead of 2*DT + 8*DB.
-// PREC = 2: "bf16x6", the default of dlwp_window_attn_f32 (the parity path): Q, K, V and P split EXACTLY into three
+// PREC = 2: "bf16x6" (dlwp_window_attn_f32 for smaller windows): Q, K, V and P split EXACTLY into three
 //           bf16 parts each (common.hpp), six cross products per contraction accumulated in fp32 -- fp32-GEMM
 //           accuracy on the bf16 matrix pipe: 6 x 16 cycles per 32-deep k-step instead of 8 x 32 for the same
-//           contraction on fp32 MFMA, and the bf16 pipe leaves the fp32 lanes to the softmax.
+//           contraction on fp32 MFMA.  Measured: the same time per call as PREC 0 (872 / 910 us vs 859 / 927 us at the
+//           Swin C3 shape) -- 45 % more VALU instructions for the splits eat what the matrix pipe saves.
 // LON4: the window's fastest axis is a multiple of 4, so the 4 keys a lane owns in a 16-key block
 //       (rows 4g..4g+3 of the accumulator) are consecutive along longitude: ONE bias index per 4 scores.
 // All score arithmetic is in the log2 domain (q scale, bias table and mask are pre-multiplied by
@@ -492,7 +493,21 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
 }  // namespace wattn
 }  // namespace dlwp
 
-namespace dlwp { namespace fno { bool use_bf16x6_layer(); } }   // fno2d.hip: the process-wide fp32-MFMA / bf16x6 switch
+// which fp32-accurate form dlwp_window_attn_f32 runs: 0 fp32 MFMA, 1 bf16x6, -1 by window size (default)
+static int g_wattn_bf16x6 = -2;   // -2: read DLWP_WATTN_BF16X6 once
+static int wattn_bf16x6_mode() {
+  if (g_wattn_bf16x6 == -2) {
+    const char* e = getenv("DLWP_WATTN_BF16X6");
+    g_wattn_bf16x6 = e ? (atoi(e) > 0 ? 1 : (atoi(e) < 0 ? -1 : 0)) : -1;
+  }
+  return g_wattn_bf16x6;
+}
+
+extern "C" int32_t dlwp_set_window_attn_bf16x6(int32_t mode) {
+  const int32_t prev = wattn_bf16x6_mode();
+  g_wattn_bf16x6 = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
+  return prev;
+}
 
 using namespace dlwp;
 using namespace dlwp::wattn;
@@ -599,9 +614,14 @@ static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, cons
 
 extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
                                         const float* table, float* out, int32_t batch, void* stream) {
-  // fp32-accurate either way: bf16x6 on the bf16 matrix pipe by default, the plain fp32-MFMA kernel under
-  // dlwp_set_fp32_mfma(1) / DLWP_FP32_MFMA=1 (cross-check, like the FNO kernels)
-  return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, dlwp::fno::use_bf16x6_layer() ? 2 : 0);
+  // fp32-accurate either way.  By default (mode -1) by window size, as measured: whole-map windows (Swin C3, 2048
+  // tokens) take the same time per call in both forms -- the kernel is bound by its VALU work and the splits add what
+  // the cheaper MFMAs give back -- and keep the fp32-MFMA kernel; small windows (Pangu C5, 144 tokens, head_dim 32)
+  // are 4 % faster per model step with bf16x6.  dlwp_set_window_attn_bf16x6(0 / 1) forces one form (cross-check).
+  const int mode = wattn_bf16x6_mode();
+  const int n_win = u ? u->window[0] * u->window[1] * u->window[2] : 0;
+  const bool x6 = mode > 0 || (mode < 0 && n_win < 512);
+  return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, x6 ? 2 : 0);
 }
 
 extern "C" int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,

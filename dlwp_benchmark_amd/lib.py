@@ -45,6 +45,7 @@ SIGNATURES = {
     "dlwp_last_error": (c_char_p, []),
     "dlwp_device_count": (c_int32, []),
     "dlwp_set_fp32_mfma": (c_int32, [c_int32]),
+    "dlwp_set_window_attn_bf16x6": (c_int32, [c_int32]),
     "dlwp_fno2d_plan_create": (c_int32, [POINTER(c_void_p), POINTER(FNO2dDesc), c_void_p]),
     "dlwp_fno2d_plan_destroy": (c_int32, [c_void_p]),
     "dlwp_fno2d_workspace_bytes": (c_size_t, [c_void_p, c_int32]),

@@ -195,10 +195,12 @@ typedef struct dlwp_wattn_desc {
   float scale;            /* qk scale (head_dim ** -0.5 unless overridden)                     */
 } dlwp_wattn_desc;
 
-/* fp32-accurate (the parity path).  Both contractions run on the bf16 matrix pipe as exact three-way bf16 splits of
- * Q, K, V and P with six cross products each ("bf16x6": fp32-GEMM accuracy, 1e-5 per-step parity with the reference);
- * dlwp_set_fp32_mfma(1) / DLWP_FP32_MFMA=1 selects the plain v_mfma_f32_16x16x4_f32 kernel instead (cross-check).
- * tokens * 3 * heads * head_dim must stay below 2^31 (token offsets are 32-bit). */
+/* fp32-accurate window attention (the parity path), in one of two independent forms of the two contractions:
+ * fp32 operands on v_mfma_f32_16x16x4_f32, or exact three-way bf16 splits of Q, K, V and P with six cross products each
+ * on the bf16 matrix pipe ("bf16x6").  dlwp_set_window_attn_bf16x6(mode): 0 fp32 MFMA, 1 bf16x6, -1 (default) by window
+ * size as measured (>= 512 tokens per window: fp32 MFMA, same time; smaller: bf16x6, faster); returns the previous mode;
+ * env DLWP_WATTN_BF16X6 sets the initial one.  tokens * 3 * heads * head_dim must stay below 2^31. */
+int32_t dlwp_set_window_attn_bf16x6(int32_t mode);
 int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* desc, const float* qkv_dev,
                              const float* qkv_bias_dev, const float* table_dev, float* out_dev,
                              int32_t batch, void* stream);

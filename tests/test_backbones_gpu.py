@@ -83,10 +83,9 @@ def test_bf16_attention_stays_close_to_reference(tag):
 
 @pytest.mark.parametrize("tag", ["swin_e32_32x64", "pangu_e48_32x64", "swin_c3_full"])
 def test_attention_bf16x6_matches_fp32_mfma(tag):
-    """dlwp_window_attn_f32 runs its contractions as exact three-way bf16 splits on the bf16 matrix pipe (bf16x6);
-    dlwp_set_fp32_mfma(1) selects the plain v_mfma_f32_16x16x4_f32 kernel.  Two independent implementations of the
-    same fp32 arithmetic: both must hold the 1e-5 per-step bound against the REAL reference's trajectory, and agree
-    with each other to fp32 rounding."""
+    """dlwp_window_attn_f32 has two independent fp32-accurate implementations of its contractions: fp32 MFMA
+    and exact three-way bf16 splits on the bf16 matrix pipe (dlwp_set_window_attn_bf16x6(0 / 1); default: by window size).  Both must hold the 1e-5
+    per-step bound against the REAL reference's trajectory, and agree with each other to fp32 rounding."""
     import dlwp_benchmark_amd.models as M
     from dlwp_benchmark_amd import lib as _lib
     from dlwp_benchmark_amd.weights import fill_by_spec
@@ -103,20 +102,20 @@ def test_attention_bf16x6_matches_fp32_mfma(tag):
     dev = lambda t: t.to("cuda:0") if t is not None else None
     lib = _lib.load()
     outs = {}
-    prev = lib.dlwp_set_fp32_mfma(0)
+    prev = lib.dlwp_set_window_attn_bf16x6(-1)
     try:
         for mode in (0, 1):
-            lib.dlwp_set_fp32_mfma(mode)
+            lib.dlwp_set_window_attn_bf16x6(mode)
             outs[mode] = model(constants=dev(constants), prescribed=dev(prescribed), prognostic=dev(prognostic))
             torch.cuda.synchronize()
     finally:
-        lib.dlwp_set_fp32_mfma(prev)
+        lib.dlwp_set_window_attn_bf16x6(prev)
     want = torch.from_numpy(g["y"])
     for mode, got in outs.items():
         errs = per_step_rel_l2(got, want)
         assert max(errs) <= TOL, f"{tag} mode {mode}: per-step rel L2 {['%.2e' % e for e in errs]}"
     cross = per_step_rel_l2(outs[0], outs[1])
-    print(tag, "bf16x6 vs fp32-MFMA attention, per-step rel L2:", ["%.2e" % e for e in cross])
+    print(tag, "fp32-MFMA vs bf16x6 attention, per-step rel L2:", ["%.2e" % e for e in cross])
     assert max(cross) <= 5e-6
     assert not torch.equal(outs[0], outs[1]), "both modes bit-identical: is the switch wired to the attention kernel?"
 
