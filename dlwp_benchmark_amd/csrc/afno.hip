@@ -114,8 +114,11 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
   constexpr int BS = 16;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const long long plane = (long long)p.H * p.Wf;
-  const int kt = (p.km + 15) / 16;                       // 16-point tiles per spectrum row
-  const int nrows = p.row_hi - p.row_lo;
+  // every 16-column tile of every row is visited: kept points are mixed, the rest of the row (columns >= km) and the
+  // rows outside [row_lo, row_hi) are written as zeros by the same pass -- whole rows leave the kernel contiguously
+  // (the separate zero-fill launch + the half-row writes of the first version: 103 + 47 us per call at C4)
+  const int kt = (p.Wf + 15) / 16;                       // 16-point tiles per spectrum row
+  const int nrows = p.H;
   const long long ntiles = (long long)p.B * nrows * kt;
   // wave w of the workgroup owns channel block w (w + 4, ...): its weights are gathered into registers ONCE and
   // reused for every 16-point tile the workgroup visits
@@ -152,11 +155,20 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
     }
     for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
       const int tile = (int)(t % kt);
-      const int h = p.row_lo + (int)((t / kt) % nrows);
+      const int h = (int)((t / kt) % nrows);
       const int b = (int)(t / ((long long)kt * nrows));
       const int col = tile * 16 + j;
-      const bool live = col < p.km;
-      const long long base = (long long)b * p.C * plane + (long long)h * p.Wf + (live ? col : 0);
+      const bool kept_tile = h >= p.row_lo && h < p.row_hi && tile * 16 < p.km;   // wave-uniform
+      const bool live = kept_tile && col < p.km;
+      const bool in_row = col < p.Wf;
+      const long long base = (long long)b * p.C * plane + (long long)h * p.Wf + (in_row ? col : 0);
+      if (!kept_tile) {
+        if (in_row) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p.y[base + (long long)(blk * BS + 4 * g + r) * plane] = float2{0.f, 0.f};
+        }
+        continue;
+      }
       // ---- layer 1
       float2 xin[4];
 #pragma unroll
@@ -182,23 +194,14 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) d2[nt] = mfma16x16x4(a2[nt][s], d1[s >> 2][s & 3], d2[nt]);
       }
-      if (live) {
+      if (in_row) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           p.y[base + (long long)(blk * BS + 4 * g + r) * plane] =
-              float2{softshrink(d2[0][r], p.lambd) * p.out_scale, softshrink(d2[1][r], p.lambd) * p.out_scale};
+              live ? float2{softshrink(d2[0][r], p.lambd) * p.out_scale, softshrink(d2[1][r], p.lambd) * p.out_scale}
+                   : float2{0.f, 0.f};
       }
     }
-  }
-}
-
-// zeros outside the kept rows / columns (the MFMA kernel writes only kept points)
-__global__ __launch_bounds__(256) void afno_zero_fill_kernel(const Params p) {
-  const long long total = (long long)p.B * p.C * p.H * p.Wf;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int w = (int)(i % p.Wf);
-    const int h = (int)((i / p.Wf) % p.H);
-    if (w >= p.km || h < p.row_lo || h >= p.row_hi) p.y[i] = float2{0.f, 0.f};
   }
 }
 
@@ -238,9 +241,8 @@ extern "C" int32_t dlwp_afno2d_mix_scaled_f32(const float* xf, float* yf, const 
     case 4: hipLaunchKernelGGL(afno::afno_mix_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
     case 8: hipLaunchKernelGGL(afno::afno_mix_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
     case 16: {
-      // MFMA form: kept points on the matrix lanes, zeros elsewhere by a plain fill
-      hipLaunchKernelGGL(afno::afno_zero_fill_kernel, dim3(256 * 8), dim3(256), 0, s, p);
-      const long long tiles = (long long)batch * (p.row_hi - p.row_lo) * ((p.km + 15) / 16);
+      // MFMA form: kept points on the matrix lanes, zeros elsewhere from the same pass
+      const long long tiles = (long long)batch * H * ((Wf + 15) / 16);
       long long wg = tiles;
       if (wg > 256 * 8) wg = 256 * 8;
       hipLaunchKernelGGL(afno::afno_mix_mfma16_kernel, dim3((unsigned)(wg > 0 ? wg : 1)), dim3(256), 0, s, p);
