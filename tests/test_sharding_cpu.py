@@ -71,3 +71,80 @@ def test_two_rank_gather_matches_single_process():
     want = ShardedRollout(ToyBackbone(), world_size=1)(prescribed=presc, prognostic=prog)
     for r in range(world):
         assert torch.equal(ret[r], want), f"rank {r} gathered trajectory differs"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's default collective (`--collect metrics`, SURVEY section 8e "when only RMSE is needed"): every rank reduces
+# its shard to [4, K, C] double sums (on the GPU: dlwp_weighted_error_sums_f32) and ONE all-reduce moves sums + sample
+# count.  Here the per-rank sums come from a CPU stand-in of that kernel; what is under test is the cross-rank part
+# of RolloutMetrics (gloo, world_size 2, UNEQUAL shards) against the oracle's metric restatement on the whole batch.
+# ---------------------------------------------------------------------------------------------------------------
+class _CpuSumsMetrics:
+    """RolloutMetrics with the HIP sums kernel replaced by its definition (include/dlwp_hip.h) in float64 torch."""
+
+    def __new__(cls, lats, std, clim):
+        from dlwp_benchmark_amd.metrics import RolloutMetrics
+
+        class M(RolloutMetrics):
+            def sums(self, out, target):
+                w = self.latw.double()[None, None, None, :, None]
+                s = (self.std.double() if self.std is not None else torch.ones(out.shape[2], dtype=torch.float64))
+                s = s[None, None, :, None, None]
+                o, t = out.double() * s, target.double() * s
+                res = torch.zeros(4, out.shape[1], out.shape[2], dtype=torch.float64)
+                res[0] = (w * (o - t) ** 2).sum(dim=(0, 3, 4))
+                if self.clim is not None:
+                    c = self.clim.double()[None] * s
+                    res[1] = (w * (o - c) * (t - c)).sum(dim=(0, 3, 4))
+                    res[2] = (w * (o - c) ** 2).sum(dim=(0, 3, 4))
+                    res[3] = (w * (t - c) ** 2).sum(dim=(0, 3, 4))
+                return res
+
+        return M(lats, std=std, climatology=clim)
+
+
+def _metric_inputs():
+    g = torch.Generator().manual_seed(11)
+    out = torch.randn(5, 3, 2, 8, 16, generator=g)
+    tar = out + 0.3 * torch.randn(5, 3, 2, 8, 16, generator=g)
+    clim = 0.1 * torch.randn(3, 2, 8, 16, generator=g)
+    lats = torch.linspace(-78.75, 78.75, 8)
+    std = torch.tensor([2.0, 0.5])
+    return out, tar, clim, lats, std
+
+
+def _metrics_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out, tar, clim, lats, std = _metric_inputs()
+        lo, hi = shard_bounds(out.shape[0], world, rank)   # 3 + 2 samples
+        scorer = _CpuSumsMetrics(lats, std, clim)
+        res = scorer(out[lo:hi].contiguous(), tar[lo:hi].contiguous(), world_size=world)
+        ret[rank] = (res["rmse"], res["acc"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_metric_allreduce_matches_whole_batch_oracle():
+    from oracle.restate.metrics import lat_weighted_metrics
+
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_metrics_worker, args=(world, port, ret), nprocs=world, join=True)
+    out, tar, clim, lats, std = _metric_inputs()
+    rmse, acc = lat_weighted_metrics(out.numpy(), tar.numpy(), lats.numpy(), std=std.numpy(), climatology=clim.numpy())
+    single = _CpuSumsMetrics(lats, std, clim)(out, tar, world_size=1)   # same class, whole batch, no collective
+    for r in range(world):
+        got_rmse, got_acc = ret[r]
+        # the cross-rank reduction itself: exact up to the order of two float64 additions
+        assert torch.allclose(got_rmse, single["rmse"], rtol=1e-13, atol=0), f"rank {r} RMSE vs single process"
+        assert torch.allclose(got_acc, single["acc"], rtol=1e-13, atol=1e-15), f"rank {r} ACC vs single process"
+        # and against the oracle's restatement of evaluate.py:786-821 (RolloutMetrics keeps its latitude weights and
+        # scales in float32, hence 1e-7)
+        assert torch.allclose(got_rmse, torch.from_numpy(rmse), rtol=1e-7, atol=0), f"rank {r} RMSE"
+        assert torch.allclose(got_acc, torch.from_numpy(acc), rtol=1e-7, atol=1e-9), f"rank {r} ACC"
