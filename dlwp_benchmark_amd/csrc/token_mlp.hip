@@ -31,6 +31,13 @@ struct Params {
   long long T;
   int hid;
   float ln_eps;         // LN variant: n is the un-normalised token, LayerNorm (affine folded into W1 / b1) happens here
+  // NEXT variant: additionally emit LayerNorm(out) with its own affine parameters CHANNELS-FIRST, [T / HW][C][HW] --
+  // what the next AFNO block's norm1 + layout change would compute from `out` in a separate pass
+  float* next_cf;
+  const float* next_gamma;
+  const float* next_beta;
+  float next_eps;
+  long long HW;         // tokens per sample (multiple of 32)
   unsigned long long* trace;   // diagnostics (DLWP_TMLP_TRACE): [wave of workgroup 0][256] s_memtime stamps, or null
 };
 
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
 __device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
 
-template <int KS, int OT, bool RESID, bool LN>
+template <int KS, int OT, bool RESID, bool LN, bool NEXT>
 __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   constexpr int C = 32 * KS;
   static_assert(OT * 16 == C, "square MLP");
@@ -102,7 +109,9 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   u32x4* s_w2 = s_w1 + (size_t)ntile * KS * 2 * 64;    // [npair][2][OT][64]
   float* s_b1 = reinterpret_cast<float*>(s_w2 + (size_t)npair * 2 * OT * 64);
   int* s_next = reinterpret_cast<int*>(s_b1 + p.hid);   // the workgroup's pass counter
+  float* s_ng = reinterpret_cast<float*>(s_next + 4);   // NEXT: [C] gamma, [C] beta of the emitted LayerNorm
   if (tid == 0) *s_next = 0;
+  if (NEXT && tid < 2 * C) s_ng[tid] = tid < C ? p.next_gamma[tid] : p.next_beta[tid - C];
   {
     // all loads of a round in flight before the first LDS write (a load -> wait -> write loop took ~90 us for the 128 KB)
     auto stage = [&](u32x4* dst, const u32x4* src, int n) {
@@ -307,6 +316,41 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         if (live[q]) *reinterpret_cast<f32x4*>(p.out + tok[q] * C + 16 * ot + 4 * g) = acc2[ot][q];
+    if (NEXT) {
+      // LayerNorm of the finished tokens (two-pass statistics over the 4 g lanes of a token), written channels-first:
+      // for a fixed channel the 16 tokens of a lane group are 64 contiguous bytes, the other q continues them
+      const long long bsample = (pass * 32) / p.HW;             // the 32 tokens of a pass share their sample
+      const long long hw0 = pass * 32 - bsample * p.HW;
+      float* dst = p.next_cf + bsample * C * p.HW + hw0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) sum += (acc2[ot][q][0] + acc2[ot][q][1]) + (acc2[ot][q][2] + acc2[ot][q][3]);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dlt = acc2[ot][q][r] - mean;
+            sq = fmaf(dlt, dlt, sq);
+          }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / C) + p.next_eps);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ng + 16 * ot + 4 * g);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ng + C + 16 * ot + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (live[q]) dst[(long long)(16 * ot + 4 * g + r) * p.HW + 16 * q + j] = fmaf((acc2[ot][q][r] - mean) * rstd, gm[r], bt[r]);
+        }
+      }
+    }
   }
   stamp();
   if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 256 + 255] = __builtin_amdgcn_s_memrealtime();
@@ -319,7 +363,7 @@ using namespace dlwp;
 
 static bool token_mlp_shape_ok(int C, int hid, size_t* lds) {
   if (C != 64 || hid < 64 || hid % 64) return false;
-  const size_t bytes = (tmlp::n_w1hm(hid, C / 32) + tmlp::n_w2hm(hid, C / 16)) * 16 + (size_t)hid * 4 + 16;
+  const size_t bytes = (tmlp::n_w1hm(hid, C / 32) + tmlp::n_w2hm(hid, C / 16)) * 16 + (size_t)hid * 4 + 16 + (size_t)2 * C * 4;
   if (lds) *lds = bytes;
   return bytes <= 160 * 1024;
 }
@@ -345,10 +389,18 @@ extern "C" int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_
   return DLWP_OK;
 }
 
-extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev, const void* packed_dev,
-                                      const float* b1_dev, const float* b2_dev, float* out_dev, int64_t tokens,
-                                      int32_t channels, int32_t hidden, float ln_eps, void* stream) {
+static int32_t token_mlp_impl(const float* n_dev, const float* resid_dev, const void* packed_dev, const float* b1_dev,
+                              const float* b2_dev, float* out_dev, int64_t tokens, int32_t channels, int32_t hidden,
+                              float ln_eps, const float* next_gamma_dev, const float* next_beta_dev, float next_eps,
+                              float* next_cf_dev, int64_t tokens_per_sample, void* stream) {
   const bool ln = ln_eps >= 0.f;
+  const bool next = next_cf_dev != nullptr;
+  if (next) {
+    DLWP_REQUIRE(next_gamma_dev && next_beta_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+    DLWP_REQUIRE(tokens_per_sample > 0 && tokens_per_sample % 32 == 0 && tokens % tokens_per_sample == 0,
+                 DLWP_ERR_UNSUPPORTED, "token MLP: tokens per sample %lld must be a multiple of 32 and divide %lld tokens",
+                 (long long)tokens_per_sample, (long long)tokens);
+  }
   DLWP_REQUIRE(n_dev && packed_dev && (b1_dev || ln) && out_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(tokens > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
   size_t lds = 0;
@@ -367,6 +419,11 @@ extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev
   p.w2l = p.w1l + tmlp::n_w1l(hidden, KS);
   p.b1 = ln ? reinterpret_cast<const float*>(p.w2l + tmlp::n_w2l(hidden, OT)) : b1_dev;
   p.ln_eps = ln_eps;
+  p.next_cf = next_cf_dev;
+  p.next_gamma = next_gamma_dev;
+  p.next_beta = next_beta_dev;
+  p.next_eps = next_eps;
+  p.HW = tokens_per_sample;
   p.T = tokens;
   p.hid = hidden;
   p.trace = nullptr;
@@ -380,8 +437,20 @@ extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev
   }
   const long long npass = (tokens + 31) / 32;
   const unsigned grid = (unsigned)(npass < 8 * 256 ? (npass + 7) / 8 : 256);
-  auto kern = ln ? (resid_dev ? tmlp::token_mlp_kernel<2, 4, true, true> : tmlp::token_mlp_kernel<2, 4, false, true>)
-                 : (resid_dev ? tmlp::token_mlp_kernel<2, 4, true, false> : tmlp::token_mlp_kernel<2, 4, false, false>);
+  void (*kern)(const tmlp::Params) = nullptr;
+#define DLWP_TM(R_, L_, N_) kern = tmlp::token_mlp_kernel<2, 4, R_, L_, N_>
+  const int sel = (resid_dev ? 4 : 0) | (ln ? 2 : 0) | (next ? 1 : 0);
+  switch (sel) {
+    case 0: DLWP_TM(false, false, false); break;
+    case 1: DLWP_TM(false, false, true); break;
+    case 2: DLWP_TM(false, true, false); break;
+    case 3: DLWP_TM(false, true, true); break;
+    case 4: DLWP_TM(true, false, false); break;
+    case 5: DLWP_TM(true, false, true); break;
+    case 6: DLWP_TM(true, true, false); break;
+    default: DLWP_TM(true, true, true); break;
+  }
+#undef DLWP_TM
   DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   DLWP_HIP_CHECK(hipGetLastError());
@@ -400,4 +469,21 @@ extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev
     ++traced;
   }
   return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev, const void* packed_dev,
+                                      const float* b1_dev, const float* b2_dev, float* out_dev, int64_t tokens,
+                                      int32_t channels, int32_t hidden, float ln_eps, void* stream) {
+  return token_mlp_impl(n_dev, resid_dev, packed_dev, b1_dev, b2_dev, out_dev, tokens, channels, hidden, ln_eps, nullptr,
+                        nullptr, 0.f, nullptr, 0, stream);
+}
+
+extern "C" int32_t dlwp_token_mlp_emit_norm_f32(const float* n_dev, const float* resid_dev, const void* packed_dev,
+                                                const float* b1_dev, const float* b2_dev, float* out_dev,
+                                                int64_t tokens, int32_t channels, int32_t hidden, float ln_eps,
+                                                const float* next_gamma_dev, const float* next_beta_dev, float next_eps,
+                                                float* next_cf_dev, int64_t tokens_per_sample, void* stream) {
+  DLWP_REQUIRE(next_cf_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  return token_mlp_impl(n_dev, resid_dev, packed_dev, b1_dev, b2_dev, out_dev, tokens, channels, hidden, ln_eps,
+                        next_gamma_dev, next_beta_dev, next_eps, next_cf_dev, tokens_per_sample, stream);
 }

@@ -93,6 +93,9 @@ SIGNATURES = {
     "dlwp_token_mlp_pack_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "dlwp_token_mlp_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32,
                                      c_int32, c_float, c_void_p]),
+    "dlwp_token_mlp_emit_norm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64,
+                                               c_int32, c_int32, c_float, c_void_p, c_void_p, c_float, c_void_p,
+                                               ctypes.c_int64, c_void_p]),
     "dlwp_weighted_error_sums_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                c_int32, c_int32, c_int32, c_void_p]),
     "dlwp_spectral_conv2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),

@@ -63,10 +63,13 @@ class _Block(nn.Module):
         self._mlp_packed = ops.TokenMlpWeights()   # derived operand layout, not part of the state dict
         self._mlp_fused = None
 
-    def forward(self, x):
+    def forward(self, x, l_cf=None, next_norm=None):
         """fourcastnet.py:180-193 (double skip).  LayerNorm1 writes channels-first for the FFT; the inverse
-        layout change is fused with `+ bias`, the first skip and LayerNorm2 (dlwp_afno_merge_f32)."""
-        l_cf = ops.layernorm_nhwc_to_nchw(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        layout change is fused with `+ bias`, the first skip and LayerNorm2 (dlwp_afno_merge_f32).
+        l_cf: norm1(x) channels-first if the previous block's MLP kernel already produced it; next_norm: the next
+        block's norm1, to be produced by this block's MLP kernel.  Returns (x_out, l_cf of the next block or None)."""
+        if l_cf is None:
+            l_cf = ops.layernorm_nhwc_to_nchw(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         f_cf = self.filter.filter_cf(l_cf)
         m = self.mlp
         if self._mlp_fused is None:
@@ -76,14 +79,19 @@ class _Block(nn.Module):
             # (norm2's affine part lives in the packed fc1 operands; the merge kernel only has to produce the sum)
             s, _ = ops.afno_merge(f_cf, l_cf, x, None, None, self.norm2.eps, want_norm=False)
             packed = self._mlp_packed.get(m.fc1.weight, m.fc2.weight, self.norm2.weight, self.norm2.bias, m.fc1.bias)
-            return ops.token_mlp(s, s, packed, None, m.fc2.bias, m.fc1.out_features, out=s, ln_eps=self.norm2.eps)
+            emit = None
+            if next_norm is not None and (s.shape[1] * s.shape[2]) % 32 == 0:
+                emit = (next_norm.weight, next_norm.bias, next_norm.eps)
+            res = ops.token_mlp(s, s, packed, None, m.fc2.bias, m.fc1.out_features, out=s, ln_eps=self.norm2.eps,
+                                emit_norm=emit)
+            return res if emit is not None else (res, None)
         # other widths: second skip folded into the fc2 GEMM -- the merge kernel stores sum + fc2.bias, addmm adds
         # onto it (beta = 1)
         s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, sum_bias=m.fc2.bias)
         hid = torch.nn.functional.gelu(torch.nn.functional.linear(n, m.fc1.weight, m.fc1.bias))
         c = x.shape[-1]
         s.view(-1, c).addmm_(hid.view(-1, hid.shape[-1]), m.fc2.weight.t())   # in place: no copy of the addend
-        return s
+        return s, None
 
 
 class _PatchEmbed(nn.Module):
@@ -133,8 +141,10 @@ class FourCastNet(HipBackbone):
             tok = torch.empty(x.shape, device=x.device, dtype=x.dtype)
             x = torch.add(x, self.pos_embed, out=tok) if self.use_pos_embed else tok.copy_(x)
         x = x.reshape(b, self.h, self.w, self.embed_dim)
-        for blk in self.blocks:
-            x = blk(x)
+        l_cf = None   # norm1 of the next block, channels-first, when the previous block's MLP kernel produced it
+        for i, blk in enumerate(self.blocks):
+            nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
+            x, l_cf = blk(x, l_cf, nxt)
         x = self.head(x)
         p1, p2 = self.patch_size
         return x.view(b, self.h, self.w, p1, p2, self.out_chans).permute(0, 5, 1, 3, 2, 4).reshape(

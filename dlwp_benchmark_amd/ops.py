@@ -335,10 +335,12 @@ class TokenMlpWeights:
 
 def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tensor, b1: Optional[torch.Tensor],
               b2: Optional[torch.Tensor], hidden: int, out: Optional[torch.Tensor] = None,
-              ln_eps: Optional[float] = None) -> torch.Tensor:
+              ln_eps: Optional[float] = None, emit_norm=None):
     """out = resid + b2 + fc2(gelu(fc1(n)))  over the last dimension (fourcastnet.py:41-57, :191-192), one launch.
     With `ln_eps` the kernel first LayerNorms `n` (packed must carry the folded affine part and fc1 bias, see
-    TokenMlpWeights.get; b1 is then unused).  `out` may be `resid` / `n` itself (in place)."""
+    TokenMlpWeights.get; b1 is then unused).  `out` may be `resid` / `n` itself (in place).
+    emit_norm = (weight, bias, eps) of the NEXT block's first LayerNorm: n must be [B, H, W, C]; returns
+    (out, LayerNorm(out) channels-first [B, C, H, W]) -- the next block's `layernorm_nhwc_to_nchw` for free."""
     _lib.require_cuda_tensor(n, "n")
     n = n.contiguous()
     c = n.shape[-1]
@@ -353,14 +355,23 @@ def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tens
     elif out.shape != n.shape or not out.is_contiguous():
         raise _lib.DlwpError("token MLP: out must be contiguous and shaped like n")
     lib = _lib.load()
+    common = (n.data_ptr(), resid.data_ptr() if resid is not None else None, packed.data_ptr(),
+              b1.contiguous().data_ptr() if b1 is not None else None,
+              b2.contiguous().data_ptr() if b2 is not None else None,
+              out.data_ptr(), n.numel() // c, c, int(hidden), float(ln_eps) if ln_eps is not None else -1.0)
     with torch.cuda.device(n.device):
-        _lib.check(lib.dlwp_token_mlp_f32(n.data_ptr(), resid.data_ptr() if resid is not None else None, packed.data_ptr(),
-                                          b1.contiguous().data_ptr() if b1 is not None else None,
-                                          b2.contiguous().data_ptr() if b2 is not None else None,
-                                          out.data_ptr(), n.numel() // c, c, int(hidden),
-                                          float(ln_eps) if ln_eps is not None else -1.0, _lib.stream_ptr()),
-                   "dlwp_token_mlp_f32")
-    return out
+        if emit_norm is None:
+            _lib.check(lib.dlwp_token_mlp_f32(*common, _lib.stream_ptr()), "dlwp_token_mlp_f32")
+            return out
+        if n.dim() != 4:
+            raise _lib.DlwpError("token MLP emit_norm: n must be [B, H, W, C]")
+        gamma, beta, eps = emit_norm
+        b, h, w, _ = n.shape
+        nxt = torch.empty(b, c, h, w, device=n.device, dtype=torch.float32)
+        _lib.check(lib.dlwp_token_mlp_emit_norm_f32(*common, gamma.contiguous().data_ptr(), beta.contiguous().data_ptr(),
+                                                    float(eps), nxt.data_ptr(), h * w, _lib.stream_ptr()),
+                   "dlwp_token_mlp_emit_norm_f32")
+    return out, nxt
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

@@ -335,6 +335,15 @@ int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, const 
 int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev, const void* packed_dev, const float* b1_dev,
                            const float* b2_dev, float* out_dev, int64_t tokens, int32_t channels, int32_t hidden,
                            float ln_eps, void* stream);
+/* dlwp_token_mlp_f32 that ALSO emits next = LayerNorm(out; next_gamma, next_beta, next_eps) CHANNELS-FIRST,
+ * next_cf_dev [tokens / tokens_per_sample][channels][tokens_per_sample]: what the following AFNO block computes first
+ * (`norm1`, fourcastnet.py:182, + the layout rfft2 wants), taken from the accumulators instead of a separate pass over
+ * `out`.  tokens_per_sample % 32 == 0 and tokens % tokens_per_sample == 0, else DLWP_ERR_UNSUPPORTED. */
+int32_t dlwp_token_mlp_emit_norm_f32(const float* n_dev, const float* resid_dev, const void* packed_dev,
+                                     const float* b1_dev, const float* b2_dev, float* out_dev, int64_t tokens,
+                                     int32_t channels, int32_t hidden, float ln_eps, const float* next_gamma_dev,
+                                     const float* next_beta_dev, float next_eps, float* next_cf_dev,
+                                     int64_t tokens_per_sample, void* stream);
 
 /* On-device evaluation sums (reference scripts/evaluate.py:786-821 `compute_metrics` + the
  * de-normalisation of :281-296): out_dev, target_dev [B, K, C, H, W]; climatology_dev [K, C, H, W] or NULL;

@@ -71,6 +71,35 @@ def test_token_mlp_fused_layernorm_matches_fp64(tokens):
     assert rel_l2(got, want) < 2e-6
 
 
+def test_token_mlp_emits_next_layernorm_channels_first():
+    """dlwp_token_mlp_emit_norm_f32: the second output must equal LayerNorm(out) moved to [B, C, H, W]
+    (what dlwp_layernorm_nhwc_to_nchw_f32 computes from `out` in the next AFNO block, fourcastnet.py:182)."""
+    from dlwp_benchmark_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    b, h, w, c, hidden, eps = 3, 8, 20, 64, 256, 1e-6
+    s = (2.0 * torch.randn(b, h, w, c, generator=gen) + 0.5).to(dev)
+    gamma2 = (1.0 + 0.2 * torch.randn(c, generator=gen)).to(dev)
+    beta2 = (0.2 * torch.randn(c, generator=gen)).to(dev)
+    gamma1 = (1.0 + 0.3 * torch.randn(c, generator=gen)).to(dev)
+    beta1 = (0.3 * torch.randn(c, generator=gen)).to(dev)
+    w1 = (torch.randn(hidden, c, generator=gen) / c ** 0.5).to(dev)
+    b1 = (0.3 * torch.randn(hidden, generator=gen)).to(dev)
+    w2 = (torch.randn(c, hidden, generator=gen) / hidden ** 0.5).to(dev)
+    b2 = (0.3 * torch.randn(c, generator=gen)).to(dev)
+    packed = ops.TokenMlpWeights().get(w1, w2, gamma2, beta2, b1)
+    plain = ops.token_mlp(s.clone(), s, packed, None, b2, hidden, ln_eps=eps)
+    buf = s.clone()
+    out, nxt = ops.token_mlp(buf, buf, packed, None, b2, hidden, out=buf, ln_eps=eps, emit_norm=(gamma1, beta1, eps))
+    assert torch.equal(out, plain)
+    want = torch.nn.functional.layer_norm(out.double(), (c,), gamma1.double(), beta1.double(), eps).permute(0, 3, 1, 2)
+    assert nxt.shape == (b, c, h, w) and nxt.is_contiguous()
+    assert rel_l2(nxt, want) < 1e-6
+    ref_kernel = ops.layernorm_nhwc_to_nchw(out, gamma1, beta1, eps)
+    assert rel_l2(nxt, ref_kernel) < 1e-6
+
+
 def test_token_mlp_repacks_after_weight_update():
     from dlwp_benchmark_amd import ops
 
