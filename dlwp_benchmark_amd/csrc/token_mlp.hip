@@ -38,6 +38,10 @@ struct Params {
   const float* next_beta;
   float next_eps;
   long long HW;         // tokens per sample (multiple of 32)
+  // MERGE variant (the whole tail of an AFNO block): the fc1 input / residual is sum = f_cf + l_cf + n, with f_cf, l_cf
+  // CHANNELS-FIRST [T / HW][C][HW] (irfft2 output and the `+ bias` path) and n the block's input tokens
+  const float* f_cf;
+  const float* l_cf;
   unsigned long long* trace;   // diagnostics (DLWP_TMLP_TRACE): [wave of workgroup 0][256] s_memtime stamps, or null
 };
 
@@ -52,7 +56,7 @@ __host__ __device__ inline size_t n_w2l(int hid, int OT) { return (size_t)(hid /
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ b1, unsigned* __restrict__ dst, int C,
-                                                   int hid) {
+                                                   int hid, int merged_layout) {
   const int KS = C / 32, OT = C / 16;
   unsigned* w1hm = dst;
   unsigned* w2hm = w1hm + n_w1hm(hid, KS) * 4;
@@ -64,7 +68,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
     if (i < n1) {
       const int d = i & 3, l = (i >> 2) & 63, tk = i >> 8;   // tk = t * KS + ks
       const int t = tk / KS, ks = tk % KS;
-      const int ch = 32 * ks + 8 * (l >> 4) + 2 * d;
+      // which channel k-slot (ks, g = l >> 4, e = 2d) of layer 1 carries: 32 ks + 8 g + e for the plain kernels (8 consecutive
+      // channels of the token row per lane), 16 (2 ks + e / 4) + 4 g + e % 4 for the MERGE kernel (the lane's B-operand
+      // channels are then exactly the channels of its accumulator rows: one set of loads feeds LayerNorm and residual)
+      const int e0 = 2 * d;
+      const int ch = merged_layout ? 16 * (2 * ks + e0 / 4) + 4 * (l >> 4) + e0 % 4 : 32 * ks + 8 * (l >> 4) + e0;
       const float* src = w1 + (size_t)(16 * t + (l & 15)) * C + ch;
       split3_pair(gamma ? src[0] * gamma[ch] : src[0], gamma ? src[1] * gamma[ch + 1] : src[1], h, m, lo);
       w1hm[((size_t)(tk * 2 + 0) * 64 + l) * 4 + d] = h;
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
 __device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
 
-template <int KS, int OT, bool RESID, bool LN, bool NEXT>
+template <int KS, int OT, bool RESID, bool LN, bool NEXT, bool MERGE = false>
 __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   constexpr int C = 32 * KS;
   static_assert(OT * 16 == C, "square MLP");
@@ -110,7 +118,9 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   float* s_b1 = reinterpret_cast<float*>(s_w2 + (size_t)npair * 2 * OT * 64);
   int* s_next = reinterpret_cast<int*>(s_b1 + p.hid);   // the workgroup's pass counter
   float* s_ng = reinterpret_cast<float*>(s_next + 4);   // NEXT: [C] gamma, [C] beta of the emitted LayerNorm
+  float* s_b2 = s_ng + 2 * C;                           // [C] fc2 bias (zeros without one)
   if (tid == 0) *s_next = 0;
+  if (tid < C) s_b2[tid] = p.b2 ? p.b2[tid] : 0.f;
   if (NEXT && tid < 2 * C) s_ng[tid] = tid < C ? p.next_gamma[tid] : p.next_beta[tid - C];
   {
     // all loads of a round in flight before the first LDS write (a load -> wait -> write loop took ~90 us for the 128 KB)
@@ -142,10 +152,12 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
     p.trace[wave * 256 + 253] = rt_entry;
     p.trace[wave * 256 + 254] = __builtin_amdgcn_s_memrealtime();
   }
-  f32x4 b2v[OT];
-#pragma unroll
-  for (int ot = 0; ot < OT; ++ot)
-    b2v[ot] = p.b2 ? *reinterpret_cast<const f32x4*>(p.b2 + 16 * ot + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // fc2 bias: read from LDS where it is needed (16 registers held across the whole kernel were the difference between
+  // 256 VGPRs with spills and none in the MERGE + NEXT variant)
+  // (g_op: an OPAQUE copy of g, refreshed every pass -- otherwise hipcc hoists these pass-invariant LDS reads out of the
+  // pass loop and keeps their 16 + 32 registers live across the whole kernel)
+  int g_op = g;
+  auto b2v = [&](int ot) { return *reinterpret_cast<const f32x4*>(s_b2 + 16 * ot + 4 * g_op); };
 
   auto load_lo = [&](int u, u32x4(&wl1)[2][KS], u32x4(&wl2)[OT]) {
 #pragma unroll
@@ -172,6 +184,14 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
     const long long pass = pass_lo + __builtin_amdgcn_readfirstlane(mine);
     if (pass >= pass_hi) break;
     stamp();
+    asm volatile("" : "+v"(g_op));
+    // channels-first views (MERGE inputs, NEXT output): the 32 tokens of a pass share their sample (HW % 32 == 0)
+    long long cf_off = 0;
+    if (MERGE || NEXT) {
+      const unsigned hw = (unsigned)p.HW, t0 = (unsigned)(pass * 32);   // tokens < 2^31 (checked on the host)
+      const unsigned bsample = t0 / hw;
+      cf_off = (long long)bsample * C * p.HW + (t0 - bsample * hw);
+    }
     long long tok[2];
     bool live[2];
 #pragma unroll
@@ -180,66 +200,115 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
       live[q] = t < p.T;
       tok[q] = live[q] ? t : p.T - 1;
     }
-    // layer-1 B operands: the token's channels 32 ks + 8 g .. + 7 (LayerNorm'd here in the LN variant: the four g lanes
-    // of a token hold its C channels between them; two-pass statistics like torch), split
     u32x4 bx[2][KS][3];
+    f32x4 acc2[OT][2];
+    if constexpr (MERGE) {
+      // sum = f + l (channels-first: for a fixed channel the lane group's 16 tokens are 64 contiguous bytes) + n (the
+      // block's input tokens); this lane's 16 channels 16 ot + 4 g + r of token (q, j) are its accumulator rows AND, with
+      // the merged k-slot layout of the packed W1, its layer-1 B operand: LayerNorm, residual and operand from one load set
+      const float* fb = p.f_cf + cf_off;
+      const float* lb = p.l_cf + cf_off;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      f32x4 v[KS][2];
+      for (int q = 0; q < 2; ++q) {
+        f32x4 sv[OT];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float* src = p.n + tok[q] * C + 32 * ks + 8 * g;
-        v[ks][0] = *reinterpret_cast<const f32x4*>(src);
-        v[ks][1] = *reinterpret_cast<const f32x4*>(src + 4);
-      }
-      if (LN) {
+        for (int ot = 0; ot < OT; ++ot) {
+          sv[ot] = *reinterpret_cast<const f32x4*>(p.n + tok[q] * C + 16 * ot + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long o = (long long)(16 * ot + 4 * g + r) * p.HW + 16 * q + j;
+            sv[ot][r] += fb[o] + lb[o];
+          }
+          acc2[ot][q] = sv[ot] + b2v(ot);
+        }
         float sum = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) sum += (v[ks][hh][0] + v[ks][hh][1]) + (v[ks][hh][2] + v[ks][hh][3]);
+        for (int ot = 0; ot < OT; ++ot) sum += (sv[ot][0] + sv[ot][1]) + (sv[ot][2] + sv[ot][3]);
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float mean = sum * (1.0f / C);
         float sq = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              v[ks][hh][k] -= mean;
-              sq = fmaf(v[ks][hh][k], v[ks][hh][k], sq);
-            }
+          for (int r = 0; r < 4; ++r) {
+            sv[ot][r] -= mean;
+            sq = fmaf(sv[ot][r], sv[ot][r], sq);
+          }
         sq += __shfl_xor(sq, 16);
         sq += __shfl_xor(sq, 32);
         const float rstd = rsqrtf(sq * (1.0f / C) + p.ln_eps);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) v[ks][hh] *= rstd;
+          for (int i = 0; i < 4; ++i) {   // k-slots 2i, 2i+1 of k-step ks = channels 16 (2 ks + i / 2) + 4 g + 2 (i % 2), + 1
+            unsigned hh, mm, ll;
+            split3_pair(sv[2 * ks + i / 2][2 * (i % 2)] * rstd, sv[2 * ks + i / 2][2 * (i % 2) + 1] * rstd, hh, mm, ll);
+            bx[q][ks][0][i] = hh;
+            bx[q][ks][1][i] = mm;
+            bx[q][ks][2][i] = ll;
+          }
       }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned hh, mm, ll;
-          split3_pair(v[ks][i / 2][2 * (i % 2)], v[ks][i / 2][2 * (i % 2) + 1], hh, mm, ll);
-          bx[q][ks][0][i] = hh;
-          bx[q][ks][1][i] = mm;
-          bx[q][ks][2][i] = ll;
-        }
-    }
-    // the residual is the accumulator's start value: acc2[ot][q][r] = out[token (q, j)][16 ot + 4 g + r]
-    f32x4 acc2[OT][2];
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    } else {
+      // layer-1 B operands: the token's channels 32 ks + 8 g .. + 7 (LayerNorm'd here in the LN variant: the four g lanes
+      // of a token hold its C channels between them; two-pass statistics like torch), split
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        acc2[ot][q] = b2v[ot];
-        if (RESID) acc2[ot][q] += *reinterpret_cast<const f32x4*>(p.resid + tok[q] * C + 16 * ot + 4 * g);
+        f32x4 v[KS][2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float* src = p.n + tok[q] * C + 32 * ks + 8 * g;
+          v[ks][0] = *reinterpret_cast<const f32x4*>(src);
+          v[ks][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        if (LN) {
+          float sum = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) sum += (v[ks][hh][0] + v[ks][hh][1]) + (v[ks][hh][2] + v[ks][hh][3]);
+          sum += __shfl_xor(sum, 16);
+          sum += __shfl_xor(sum, 32);
+          const float mean = sum * (1.0f / C);
+          float sq = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[ks][hh][k] -= mean;
+                sq = fmaf(v[ks][hh][k], v[ks][hh][k], sq);
+              }
+          sq += __shfl_xor(sq, 16);
+          sq += __shfl_xor(sq, 32);
+          const float rstd = rsqrtf(sq * (1.0f / C) + p.ln_eps);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) v[ks][hh] *= rstd;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned hh, mm, ll;
+            split3_pair(v[ks][i / 2][2 * (i % 2)], v[ks][i / 2][2 * (i % 2) + 1], hh, mm, ll);
+            bx[q][ks][0][i] = hh;
+            bx[q][ks][1][i] = mm;
+            bx[q][ks][2][i] = ll;
+          }
       }
+      // the residual is the accumulator's start value: acc2[ot][q][r] = out[token (q, j)][16 ot + 4 g + r]
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          acc2[ot][q] = b2v(ot);
+          if (RESID) acc2[ot][q] += *reinterpret_cast<const f32x4*>(p.resid + tok[q] * C + 16 * ot + 4 * g);
+        }
 
+    }
     // one hidden-tile pair; the l parts it uses (wl*) were requested one unit ago, those of the next unit (nl*) are
     // requested at the top so that their L2 latency hides behind this unit's ~1500 matrix-pipe cycles
     auto unit = [&](int u, const u32x4(&wl1)[2][KS], const u32x4(&wl2)[OT], u32x4(&nl1)[2][KS], u32x4(&nl2)[OT]) {
@@ -319,9 +388,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
     if (NEXT) {
       // LayerNorm of the finished tokens (two-pass statistics over the 4 g lanes of a token), written channels-first:
       // for a fixed channel the 16 tokens of a lane group are 64 contiguous bytes, the other q continues them
-      const long long bsample = (pass * 32) / p.HW;             // the 32 tokens of a pass share their sample
-      const long long hw0 = pass * 32 - bsample * p.HW;
-      float* dst = p.next_cf + bsample * C * p.HW + hw0;
+      float* dst = p.next_cf + cf_off;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float sum = 0.f;
@@ -343,8 +410,8 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
         const float rstd = rsqrtf(sq * (1.0f / C) + p.next_eps);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ng + 16 * ot + 4 * g);
-          const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ng + C + 16 * ot + 4 * g);
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ng + 16 * ot + 4 * g_op);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ng + C + 16 * ot + 4 * g_op);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (live[q]) dst[(long long)(16 * ot + 4 * g + r) * p.HW + 16 * q + j] = fmaf((acc2[ot][q][r] - mean) * rstd, gm[r], bt[r]);
@@ -363,7 +430,7 @@ using namespace dlwp;
 
 static bool token_mlp_shape_ok(int C, int hid, size_t* lds) {
   if (C != 64 || hid < 64 || hid % 64) return false;
-  const size_t bytes = (tmlp::n_w1hm(hid, C / 32) + tmlp::n_w2hm(hid, C / 16)) * 16 + (size_t)hid * 4 + 16 + (size_t)2 * C * 4;
+  const size_t bytes = (tmlp::n_w1hm(hid, C / 32) + tmlp::n_w2hm(hid, C / 16)) * 16 + (size_t)hid * 4 + 16 + (size_t)3 * C * 4;
   if (lds) *lds = bytes;
   return bytes <= 160 * 1024;
 }
@@ -377,14 +444,14 @@ extern "C" size_t dlwp_token_mlp_packed_bytes(int32_t channels, int32_t hidden) 
 
 extern "C" int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
                                            const float* ln_beta_dev, const float* b1_dev, int32_t channels,
-                                           int32_t hidden, void* packed_dev, void* stream) {
+                                           int32_t hidden, int32_t merged_layout, void* packed_dev, void* stream) {
   DLWP_REQUIRE(w1_dev && w2_dev && packed_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE((ln_gamma_dev == nullptr) == (ln_beta_dev == nullptr), DLWP_ERR_INVALID_ARGUMENT,
                "LayerNorm weight and bias must be given together");
   DLWP_REQUIRE(token_mlp_shape_ok(channels, hidden, nullptr), DLWP_ERR_UNSUPPORTED,
                "token MLP: channels %d (64 supported), hidden %d (multiple of 64, <= 256: weights must fit LDS)", channels, hidden);
   hipLaunchKernelGGL(tmlp::pack_kernel, dim3(64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w1_dev, w2_dev,
-                     ln_gamma_dev, ln_beta_dev, b1_dev, reinterpret_cast<unsigned*>(packed_dev), channels, hidden);
+                     ln_gamma_dev, ln_beta_dev, b1_dev, reinterpret_cast<unsigned*>(packed_dev), channels, hidden, merged_layout ? 1 : 0);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
@@ -392,11 +459,15 @@ extern "C" int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_
 static int32_t token_mlp_impl(const float* n_dev, const float* resid_dev, const void* packed_dev, const float* b1_dev,
                               const float* b2_dev, float* out_dev, int64_t tokens, int32_t channels, int32_t hidden,
                               float ln_eps, const float* next_gamma_dev, const float* next_beta_dev, float next_eps,
-                              float* next_cf_dev, int64_t tokens_per_sample, void* stream) {
+                              float* next_cf_dev, int64_t tokens_per_sample, void* stream,
+                              const float* f_cf_dev = nullptr, const float* l_cf_dev = nullptr) {
   const bool ln = ln_eps >= 0.f;
   const bool next = next_cf_dev != nullptr;
-  if (next) {
-    DLWP_REQUIRE(next_gamma_dev && next_beta_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  const bool merge = f_cf_dev != nullptr;
+  if (next) DLWP_REQUIRE(next_gamma_dev && next_beta_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  if (merge) DLWP_REQUIRE(l_cf_dev && ln, DLWP_ERR_INVALID_ARGUMENT, "the merged form needs both channels-first inputs and the fused LayerNorm");
+  if (next || merge) {
+    DLWP_REQUIRE(tokens < (1ll << 31), DLWP_ERR_UNSUPPORTED, "token MLP: too many tokens for the channels-first forms");
     DLWP_REQUIRE(tokens_per_sample > 0 && tokens_per_sample % 32 == 0 && tokens % tokens_per_sample == 0,
                  DLWP_ERR_UNSUPPORTED, "token MLP: tokens per sample %lld must be a multiple of 32 and divide %lld tokens",
                  (long long)tokens_per_sample, (long long)tokens);
@@ -424,6 +495,8 @@ static int32_t token_mlp_impl(const float* n_dev, const float* resid_dev, const 
   p.next_beta = next_beta_dev;
   p.next_eps = next_eps;
   p.HW = tokens_per_sample;
+  p.f_cf = f_cf_dev;
+  p.l_cf = l_cf_dev;
   p.T = tokens;
   p.hid = hidden;
   p.trace = nullptr;
@@ -451,6 +524,7 @@ static int32_t token_mlp_impl(const float* n_dev, const float* resid_dev, const 
     default: DLWP_TM(true, true, true); break;
   }
 #undef DLWP_TM
+  if (merge) kern = next ? tmlp::token_mlp_kernel<2, 4, true, true, true, true> : tmlp::token_mlp_kernel<2, 4, true, true, false, true>;
   DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   DLWP_HIP_CHECK(hipGetLastError());
@@ -486,4 +560,16 @@ extern "C" int32_t dlwp_token_mlp_emit_norm_f32(const float* n_dev, const float*
   DLWP_REQUIRE(next_cf_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   return token_mlp_impl(n_dev, resid_dev, packed_dev, b1_dev, b2_dev, out_dev, tokens, channels, hidden, ln_eps,
                         next_gamma_dev, next_beta_dev, next_eps, next_cf_dev, tokens_per_sample, stream);
+}
+
+extern "C" int32_t dlwp_afno_block_tail_f32(const float* f_cf_dev, const float* l_cf_dev, const float* x_nhwc_dev,
+                                            const void* packed_dev, const float* b2_dev, float* out_nhwc_dev,
+                                            int32_t batch, int64_t tokens_per_sample, int32_t channels, int32_t hidden,
+                                            float ln_eps, const float* next_gamma_dev, const float* next_beta_dev,
+                                            float next_eps, float* next_cf_dev, void* stream) {
+  DLWP_REQUIRE(f_cf_dev && l_cf_dev && x_nhwc_dev && out_nhwc_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0 && ln_eps >= 0.f, DLWP_ERR_INVALID_ARGUMENT, "bad arguments");
+  return token_mlp_impl(x_nhwc_dev, x_nhwc_dev, packed_dev, nullptr, b2_dev, out_nhwc_dev, (int64_t)batch * tokens_per_sample,
+                        channels, hidden, ln_eps, next_gamma_dev, next_beta_dev, next_eps, next_cf_dev, tokens_per_sample,
+                        stream, f_cf_dev, l_cf_dev);
 }

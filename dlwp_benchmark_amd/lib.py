@@ -90,7 +90,10 @@ SIGNATURES = {
     "dlwp_patch_embed_1x1_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, ctypes.c_int64,
                                            c_int32, c_void_p]),
     "dlwp_token_mlp_packed_bytes": (c_size_t, [c_int32, c_int32]),
-    "dlwp_token_mlp_pack_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "dlwp_token_mlp_pack_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
+                                          c_void_p]),
+    "dlwp_afno_block_tail_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64,
+                                           c_int32, c_int32, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dlwp_token_mlp_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32,
                                      c_int32, c_float, c_void_p]),
     "dlwp_token_mlp_emit_norm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64,

@@ -75,16 +75,22 @@ class _Block(nn.Module):
         if self._mlp_fused is None:
             self._mlp_fused = ops.token_mlp_supported(x.shape[-1], m.fc1.out_features)
         if self._mlp_fused:
-            # LayerNorm2 -> fc1 -> GELU -> fc2 -> + second skip (:191-192) in one launch, in place on the merged sum
-            # (norm2's affine part lives in the packed fc1 operands; the merge kernel only has to produce the sum)
+            hw = x.shape[1] * x.shape[2]
+            emit = None
+            if next_norm is not None and hw % 32 == 0:
+                emit = (next_norm.weight, next_norm.bias, next_norm.eps)
+            if hw % 32 == 0:
+                # `+ bias`, first skip, LayerNorm2, fc1 -> GELU -> fc2, second skip (:127, :187, :191-192) and the next
+                # block's norm1 in ONE launch, in place on x (norm2's affine part lives in the packed fc1 operands)
+                packed = self._mlp_packed.get(m.fc1.weight, m.fc2.weight, self.norm2.weight, self.norm2.bias, m.fc1.bias,
+                                              merged=True)
+                res = ops.afno_block_tail(f_cf, l_cf, x, packed, m.fc2.bias, m.fc1.out_features, self.norm2.eps,
+                                          emit_norm=emit, out=x if x.is_contiguous() else None)
+                return res if emit is not None else (res, None)
+            # odd token counts: merge kernel (sum only) + token MLP with LayerNorm2 fused
             s, _ = ops.afno_merge(f_cf, l_cf, x, None, None, self.norm2.eps, want_norm=False)
             packed = self._mlp_packed.get(m.fc1.weight, m.fc2.weight, self.norm2.weight, self.norm2.bias, m.fc1.bias)
-            emit = None
-            if next_norm is not None and (s.shape[1] * s.shape[2]) % 32 == 0:
-                emit = (next_norm.weight, next_norm.bias, next_norm.eps)
-            res = ops.token_mlp(s, s, packed, None, m.fc2.bias, m.fc1.out_features, out=s, ln_eps=self.norm2.eps,
-                                emit_norm=emit)
-            return res if emit is not None else (res, None)
+            return ops.token_mlp(s, s, packed, None, m.fc2.bias, m.fc1.out_features, out=s, ln_eps=self.norm2.eps), None
         # other widths: second skip folded into the fc2 GEMM -- the merge kernel stores sum + fc2.bias, addmm adds
         # onto it (beta = 1)
         s, n = ops.afno_merge(f_cf, l_cf, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, sum_bias=m.fc2.bias)

@@ -308,9 +308,10 @@ class TokenMlpWeights:
         self._buf = None
 
     def get(self, w1: torch.Tensor, w2: torch.Tensor, ln_weight: Optional[torch.Tensor] = None,
-            ln_bias: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None) -> torch.Tensor:
+            ln_bias: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None, merged: bool = False) -> torch.Tensor:
+        """merged=True: the k-slot order afno_block_tail wants (a different permutation of W1's columns)."""
         extra = [t for t in (ln_weight, ln_bias, b1) if t is not None]
-        key = tuple((t.data_ptr(), t._version) for t in (w1, w2, *extra)) + (str(w1.device), ln_weight is not None)
+        key = tuple((t.data_ptr(), t._version) for t in (w1, w2, *extra)) + (str(w1.device), ln_weight is not None, merged)
         if key != self._key:
             hid, c = w1.shape
             if tuple(w2.shape) != (c, hid):
@@ -328,7 +329,8 @@ class TokenMlpWeights:
 
             with torch.cuda.device(w1.device):
                 _lib.check(lib.dlwp_token_mlp_pack_f32(ptr(w1), ptr(w2), ptr(ln_weight), ptr(ln_bias), ptr(b1), c, hid,
-                                                       buf.data_ptr(), _lib.stream_ptr()), "dlwp_token_mlp_pack_f32")
+                                                       1 if merged else 0, buf.data_ptr(), _lib.stream_ptr()),
+                           "dlwp_token_mlp_pack_f32")
             self._key, self._buf = key, buf
         return self._buf
 
@@ -372,6 +374,34 @@ def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tens
                                                     float(eps), nxt.data_ptr(), h * w, _lib.stream_ptr()),
                    "dlwp_token_mlp_emit_norm_f32")
     return out, nxt
+
+
+def afno_block_tail(f_cf: torch.Tensor, l_cf: torch.Tensor, x_nhwc: torch.Tensor, packed: torch.Tensor,
+                    b2: Optional[torch.Tensor], hidden: int, ln_eps: float, emit_norm=None, out: Optional[torch.Tensor] = None):
+    """Everything of an AFNO block after the inverse FFT, one launch (fourcastnet.py:127, :187, :191-192):
+    sum = f_cf + l_cf + x;  out = sum + fc2(gelu(fc1(LayerNorm(sum)))).  f_cf / l_cf [B, C, H, W], x / out [B, H, W, C];
+    packed = TokenMlpWeights.get(..., norm2.weight, norm2.bias, fc1.bias, merged=True).
+    emit_norm = (weight, bias, eps) of the next block's norm1 -> returns (out, LayerNorm(out) [B, C, H, W])."""
+    for t, nm in ((f_cf, "f_cf"), (l_cf, "l_cf"), (x_nhwc, "x")):
+        _lib.require_cuda_tensor(t, nm)
+    f_cf, l_cf, x_nhwc = f_cf.contiguous(), l_cf.contiguous(), x_nhwc.contiguous()
+    b, h, w, c = x_nhwc.shape
+    if tuple(f_cf.shape) != (b, c, h, w) or tuple(l_cf.shape) != (b, c, h, w):
+        raise _lib.DlwpError("afno_block_tail: f_cf / l_cf must be [B, C, H, W] matching x [B, H, W, C]")
+    if out is None:
+        out = torch.empty_like(x_nhwc)
+    nxt = torch.empty(b, c, h, w, device=x_nhwc.device, dtype=torch.float32) if emit_norm is not None else None
+    gamma, beta, eps = emit_norm if emit_norm is not None else (None, None, 0.0)
+    lib = _lib.load()
+    with torch.cuda.device(x_nhwc.device):
+        _lib.check(lib.dlwp_afno_block_tail_f32(f_cf.data_ptr(), l_cf.data_ptr(), x_nhwc.data_ptr(), packed.data_ptr(),
+                                                b2.contiguous().data_ptr() if b2 is not None else None, out.data_ptr(), b,
+                                                h * w, c, int(hidden), float(ln_eps),
+                                                gamma.contiguous().data_ptr() if gamma is not None else None,
+                                                beta.contiguous().data_ptr() if beta is not None else None, float(eps),
+                                                nxt.data_ptr() if nxt is not None else None, _lib.stream_ptr()),
+                   "dlwp_afno_block_tail_f32")
+    return (out, nxt) if emit_norm is not None else out
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

@@ -323,6 +323,7 @@ int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_dev, const f
  *                                With ln_gamma_dev / ln_beta_dev [channels] (both or neither) the affine part of the
  *                                LayerNorm in front of fc1 (`norm2`, :191) is folded in: W1 diag(gamma), and
  *                                b1 + W1 beta (b1_dev [hidden] or NULL) is stored in the packed buffer.
+ *                                merged_layout != 0: the k-slot order dlwp_afno_block_tail_f32 wants (below).
  *   dlwp_token_mlp_f32:          ln_eps < 0: n_dev is the fc1 input, b1_dev required.  ln_eps >= 0: n_dev is the
  *                                UN-normalised token (normally the same buffer as resid_dev); the kernel normalises
  *                                it (two-pass statistics over the channels) and takes b1 from a buffer packed WITH
@@ -331,7 +332,7 @@ int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_dev, const f
 size_t dlwp_token_mlp_packed_bytes(int32_t channels, int32_t hidden);
 int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
                                 const float* ln_beta_dev, const float* b1_dev, int32_t channels, int32_t hidden,
-                                void* packed_dev, void* stream);
+                                int32_t merged_layout, void* packed_dev, void* stream);
 int32_t dlwp_token_mlp_f32(const float* n_dev, const float* resid_dev, const void* packed_dev, const float* b1_dev,
                            const float* b2_dev, float* out_dev, int64_t tokens, int32_t channels, int32_t hidden,
                            float ln_eps, void* stream);
@@ -344,6 +345,19 @@ int32_t dlwp_token_mlp_emit_norm_f32(const float* n_dev, const float* resid_dev,
                                      int32_t channels, int32_t hidden, float ln_eps, const float* next_gamma_dev,
                                      const float* next_beta_dev, float next_eps, float* next_cf_dev,
                                      int64_t tokens_per_sample, void* stream);
+
+/* The whole tail of an AFNO block in ONE launch (reference fourcastnet.py:127 `+ bias`, :187 first skip, :191 `norm2`,
+ * :41-57 `Mlp`, :192 second skip -- and, optionally, :182 `norm1` of the NEXT block):
+ *   sum = f_cf + l_cf + x;  out = sum + b2 + W2 gelu(W1 LayerNorm(sum) + b1);  next_cf = LayerNorm_next(out) channels-first
+ * f_cf_dev (irfft2 output) and l_cf_dev (norm1 output, the AFNO2D `bias` path) CHANNELS-FIRST [batch][channels][tokens_per_sample],
+ * x_nhwc_dev / out_nhwc_dev token-major (may alias), packed_dev from dlwp_token_mlp_pack_f32 WITH ln_gamma / ln_beta and
+ * merged_layout = 1, next_cf_dev (and its gamma / beta) NULL to skip the last part.  Replaces dlwp_afno_merge_f32 +
+ * dlwp_token_mlp_f32 (+ dlwp_layernorm_nhwc_to_nchw_f32 of the next block).  channels == 64, tokens_per_sample % 32 == 0. */
+int32_t dlwp_afno_block_tail_f32(const float* f_cf_dev, const float* l_cf_dev, const float* x_nhwc_dev,
+                                 const void* packed_dev, const float* b2_dev, float* out_nhwc_dev, int32_t batch,
+                                 int64_t tokens_per_sample, int32_t channels, int32_t hidden, float ln_eps,
+                                 const float* next_gamma_dev, const float* next_beta_dev, float next_eps,
+                                 float* next_cf_dev, void* stream);
 
 /* On-device evaluation sums (reference scripts/evaluate.py:786-821 `compute_metrics` + the
  * de-normalisation of :281-296): out_dev, target_dev [B, K, C, H, W]; climatology_dev [K, C, H, W] or NULL;

@@ -100,6 +100,40 @@ def test_token_mlp_emits_next_layernorm_channels_first():
     assert rel_l2(nxt, ref_kernel) < 1e-6
 
 
+@pytest.mark.parametrize("emit", [False, True])
+def test_afno_block_tail_matches_fp64(emit):
+    """dlwp_afno_block_tail_f32 = `+ bias`, first skip, norm2, Mlp, second skip (+ the next block's norm1) of the AFNO
+    block (fourcastnet.py:127, :187, :191-192, :182) against the same expression in float64."""
+    from dlwp_benchmark_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(31)
+    b, h, w, c, hidden, eps = 2, 8, 12, 64, 256, 1e-6
+    f_cf = torch.randn(b, c, h, w, generator=gen).to(dev)
+    l_cf = torch.randn(b, c, h, w, generator=gen).to(dev)
+    x = (1.5 * torch.randn(b, h, w, c, generator=gen)).to(dev)
+    g2 = (1.0 + 0.2 * torch.randn(c, generator=gen)).to(dev)
+    be2 = (0.2 * torch.randn(c, generator=gen)).to(dev)
+    g1 = (1.0 + 0.3 * torch.randn(c, generator=gen)).to(dev)
+    be1 = (0.3 * torch.randn(c, generator=gen)).to(dev)
+    w1 = (torch.randn(hidden, c, generator=gen) / c ** 0.5).to(dev)
+    b1 = (0.3 * torch.randn(hidden, generator=gen)).to(dev)
+    w2 = (torch.randn(c, hidden, generator=gen) / hidden ** 0.5).to(dev)
+    b2 = (0.3 * torch.randn(c, generator=gen)).to(dev)
+    s64 = (f_cf + l_cf).double().permute(0, 2, 3, 1) + x.double()
+    n64 = torch.nn.functional.layer_norm(s64, (c,), g2.double(), be2.double(), eps)
+    want = _reference(n64, s64, w1, b1, w2, b2)
+    packed = ops.TokenMlpWeights().get(w1, w2, g2, be2, b1, merged=True)
+    xin = x.clone()
+    res = ops.afno_block_tail(f_cf, l_cf, xin, packed, b2, hidden, eps, emit_norm=(g1, be1, eps) if emit else None, out=xin)
+    out = res[0] if emit else res
+    assert out.data_ptr() == xin.data_ptr()
+    assert rel_l2(out, want) < 2e-6
+    if emit:
+        want_n = torch.nn.functional.layer_norm(want, (c,), g1.double(), be1.double(), eps).permute(0, 3, 1, 2)
+        assert rel_l2(res[1], want_n) < 2e-6
+
+
 def test_token_mlp_repacks_after_weight_update():
     from dlwp_benchmark_amd import ops
 
