@@ -159,16 +159,22 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   int g_op = g;
   auto b2v = [&](int ot) { return *reinterpret_cast<const f32x4*>(s_b2 + 16 * ot + 4 * g_op); };
 
-  auto load_lo = [&](int u, u32x4(&wl1)[2][KS], u32x4(&wl2)[OT]) {
+  // l parts (global, L2 resident): ONE register set.  A unit re-requests its layer-1 set right after its layer-1 MFMAs have
+  // issued (they have read it) and its layer-2 set right after its layer-2 MFMAs -- for the NEXT unit (the last unit of a
+  // pass requests unit 0's again), so each load has most of a unit to land.
+  u32x4 wl1[2][KS], wl2[OT];
+  auto load_lo1 = [&](int u) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) wl1[tt][ks] = p.w1l[((2 * u + tt) * KS + ks) * 64 + lane];
+  };
+  auto load_lo2 = [&](int u) {
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) wl2[ot] = p.w2l[(u * OT + ot) * 64 + lane];
   };
-  u32x4 la1[2][KS], la2[OT], lb1[2][KS], lb2[OT];
-  load_lo(0, la1, la2);   // unit 0's; every later unit requests its successor's (the last one unit 0's again)
+  load_lo1(0);
+  load_lo2(0);
 
   // Passes are handed out dynamically inside the workgroup: the older wave of a SIMD wins the issue arbitration and
   // runs ~1.5x faster than its partner (DLWP_TMLP_TRACE: 3.9k vs 5.4k cycles per tile pair), and a wave left alone
@@ -309,10 +315,9 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
         }
 
     }
-    // one hidden-tile pair; the l parts it uses (wl*) were requested one unit ago, those of the next unit (nl*) are
-    // requested at the top so that their L2 latency hides behind this unit's ~1500 matrix-pipe cycles
-    auto unit = [&](int u, const u32x4(&wl1)[2][KS], const u32x4(&wl2)[OT], u32x4(&nl1)[2][KS], u32x4(&nl2)[OT]) {
-      load_lo(u + 1 < npair ? u + 1 : 0, nl1, nl2);
+    // one hidden-tile pair
+    auto unit = [&](int u) {
+      const int un = u + 1 < npair ? u + 1 : 0;
       // ---- layer 1 of hidden tiles 2u, 2u+1 (4 independent accumulators, term-major so that back-to-back
       //      MFMAs never depend on each other)
       f32x4 a1[2][2];
@@ -340,6 +345,8 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
             for (int q = 0; q < 2; ++q)
               a1[tt][q] = mfma16x16x32_bf16(wa[tt][kPA[term]], bx[q][ks][kPB[term]], a1[tt][q]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      load_lo1(un);
       // ---- GELU, then the 3-way split straight into layer-2 B operands
       gelu_erf8_fma(a1[0][0], a1[0][1]);
       gelu_erf8_fma(a1[1][0], a1[1][1]);
@@ -372,12 +379,12 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
             for (int q = 0; q < 2; ++q)
               acc2[oh + oo][q] = mfma16x16x32_bf16(wb[oo][kPA[term]], bg[q][kPB[term]], acc2[oh + oo][q]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      load_lo2(un);
     };
     stamp();
-    for (int u = 0; u < npair; u += 2) {   // npair is even (hidden % 64 == 0): the l-part registers ping-pong
-      unit(u, la1, la2, lb1, lb2);
-      stamp();
-      unit(u + 1, lb1, lb2, la1, la2);
+    for (int u = 0; u < npair; ++u) {
+      unit(u);
       stamp();
     }
 #pragma unroll
