@@ -1,5 +1,14 @@
-import sys, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+"""torch-profiler table of ONE FourCastNet (C4) step grouped by input shape: finds the layout copies, clones and
+elementwise passes torch inserts silently around custom kernels (how the 3 DtoD clones and 2 contiguous() copies per
+block of the first version were found)."""
+import os
+import sys
+
+import torch
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tools"))
 import bench_models as bm
 from dlwp_benchmark_amd.weights import fill_state_dict
 cls, cfg, batch, steps, (h, w) = bm.CONFIGS["C4_fourcastnet_128x256"]
