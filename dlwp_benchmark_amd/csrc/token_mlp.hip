@@ -202,31 +202,37 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
     bool live[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const long long t = pass * 32 + 16 * q + j;
+      const long long t = pass * 32 + 2 * j + q;   // the lane's two tokens are neighbours: 8-byte channels-first accesses
       live[q] = t < p.T;
       tok[q] = live[q] ? t : p.T - 1;
     }
     u32x4 bx[2][KS][3];
     f32x4 acc2[OT][2];
     if constexpr (MERGE) {
-      // sum = f + l (channels-first: for a fixed channel the lane group's 16 tokens are 64 contiguous bytes) + n (the
+      // sum = f + l (channels-first: for a fixed channel the lane group's 32 tokens are 128 contiguous bytes) + n (the
       // block's input tokens); this lane's 16 channels 16 ot + 4 g + r of token (q, j) are its accumulator rows AND, with
       // the merged k-slot layout of the packed W1, its layer-1 B operand: LayerNorm, residual and operand from one load set
       const float* fb = p.f_cf + cf_off;
       const float* lb = p.l_cf + cf_off;
+      f32x4 svq[2][OT];
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        svq[0][ot] = *reinterpret_cast<const f32x4*>(p.n + tok[0] * C + 16 * ot + 4 * g);
+        svq[1][ot] = *reinterpret_cast<const f32x4*>(p.n + tok[1] * C + 16 * ot + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long o = (long long)(16 * ot + 4 * g + r) * p.HW + 2 * j;
+          const float2 fv = *reinterpret_cast<const float2*>(fb + o), lv = *reinterpret_cast<const float2*>(lb + o);
+          svq[0][ot][r] += fv.x + lv.x;
+          svq[1][ot][r] += fv.y + lv.y;
+        }
+        const f32x4 bias2 = b2v(ot);
+        acc2[ot][0] = svq[0][ot] + bias2;
+        acc2[ot][1] = svq[1][ot] + bias2;
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        f32x4 sv[OT];
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          sv[ot] = *reinterpret_cast<const f32x4*>(p.n + tok[q] * C + 16 * ot + 4 * g);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const long long o = (long long)(16 * ot + 4 * g + r) * p.HW + 16 * q + j;
-            sv[ot][r] += fb[o] + lb[o];
-          }
-          acc2[ot][q] = sv[ot] + b2v(ot);
-        }
+        f32x4(&sv)[OT] = svq[q];
         float sum = 0.f;
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) sum += (sv[ot][0] + sv[ot][1]) + (sv[ot][2] + sv[ot][3]);
@@ -394,8 +400,9 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
         if (live[q]) *reinterpret_cast<f32x4*>(p.out + tok[q] * C + 16 * ot + 4 * g) = acc2[ot][q];
     if (NEXT) {
       // LayerNorm of the finished tokens (two-pass statistics over the 4 g lanes of a token), written channels-first:
-      // for a fixed channel the 16 tokens of a lane group are 64 contiguous bytes, the other q continues them
+      // for a fixed channel the 32 tokens of a lane group (two per lane) are 128 contiguous bytes
       float* dst = p.next_cf + cf_off;
+      float mean[2], rstd[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float sum = 0.f;
@@ -403,26 +410,28 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
         for (int ot = 0; ot < OT; ++ot) sum += (acc2[ot][q][0] + acc2[ot][q][1]) + (acc2[ot][q][2] + acc2[ot][q][3]);
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.0f / C);
+        mean[q] = sum * (1.0f / C);
         float sq = 0.f;
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float dlt = acc2[ot][q][r] - mean;
+            const float dlt = acc2[ot][q][r] - mean[q];
             sq = fmaf(dlt, dlt, sq);
           }
         sq += __shfl_xor(sq, 16);
         sq += __shfl_xor(sq, 32);
-        const float rstd = rsqrtf(sq * (1.0f / C) + p.next_eps);
+        rstd[q] = rsqrtf(sq * (1.0f / C) + p.next_eps);
+      }
+      // (the channels-first forms require tokens % 32 == 0 on the host: no partial pass, both tokens of a lane are live)
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ng + 16 * ot + 4 * g_op);
-          const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ng + C + 16 * ot + 4 * g_op);
+      for (int ot = 0; ot < OT; ++ot) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(s_ng + 16 * ot + 4 * g_op);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(s_ng + C + 16 * ot + 4 * g_op);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (live[q]) dst[(long long)(16 * ot + 4 * g + r) * p.HW + 16 * q + j] = fmaf((acc2[ot][q][r] - mean) * rstd, gm[r], bt[r]);
-        }
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<float2*>(dst + (long long)(16 * ot + 4 * g + r) * p.HW + 2 * j) =
+              float2{fmaf((acc2[ot][0][r] - mean[0]) * rstd[0], gm[r], bt[r]), fmaf((acc2[ot][1][r] - mean[1]) * rstd[1], gm[r], bt[r])};
       }
     }
   }
