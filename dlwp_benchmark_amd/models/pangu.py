@@ -235,7 +235,9 @@ class PanguWeather(HipBackbone):
         """panguweather.py:512-535 (`forward_one_step`)."""
         x = self.patchembed2d(x)
         b, c, lat, lon = x.shape
-        x = x.reshape(b, c, -1).transpose(1, 2)
+        # token-major ONCE: a transposed view here made every kernel / residual add of layer 1 copy or inherit the
+        # permuted strides again (4 full-size copies per step in the profile)
+        x = x.reshape(b, c, -1).transpose(1, 2).contiguous()
         x = self.layer1(x)
         skip = x
         x = self.layer3(self.layer2(self.downsample(x)))
