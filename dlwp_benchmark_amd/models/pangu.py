@@ -242,8 +242,18 @@ class PanguWeather(HipBackbone):
         skip = x
         x = self.layer3(self.layer2(self.downsample(x)))
         x = self.layer4(self.upsample(x))
+        pr = self.patchrecovery2d
+        if tuple(pr.conv.kernel_size) == (1, 1) and (lat, lon) == tuple(pr.img_size):
+            # 1x1 patches: ConvTranspose2d(2C -> Cg, kernel = stride = 1) is a per-token linear map, and
+            # cat([x, skip]) @ W = x @ W[:C] + skip @ W[C:] -- two thin GEMMs on the token-major tensors instead of a
+            # full-size concat, a transposed copy of it and a convolution (panguweather.py:533-535, patch_recovery.py:5-33)
+            w2 = pr.conv.weight[:, :, 0, 0]                       # [2C, Cg]
+            cc = x.shape[-1]
+            y = torch.addmm(pr.conv.bias, x.reshape(-1, cc), w2[:cc])
+            y.addmm_(skip.reshape(-1, cc), w2[cc:])
+            return y.view(b, lat, lon, -1).permute(0, 3, 1, 2).contiguous()
         out = torch.cat([x, skip], dim=-1).transpose(1, 2).reshape(b, -1, lat, lon)
-        return self.patchrecovery2d(out)
+        return pr(out)
 
     def rollout_into(self, out, constants, prescribed, prognostic, step_begin=0, step_end=-1):
         return rollout_into(self._step_fn(), self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)
