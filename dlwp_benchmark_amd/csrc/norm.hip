@@ -10,7 +10,8 @@ namespace dlwp {
 namespace norm {
 
 template <int LPR, int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pre,
+                                                        const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         long long rows, int C, float eps) {
   const int lane = threadIdx.x & 63;
@@ -19,13 +20,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long nwave = ((long long)gridDim.x * blockDim.x) >> 6;
   const int nvec = C >> 2;
-  f32x4 gm[NV], bt[NV];
+  f32x4 gm[NV], bt[NV], pb[NV];   // pb: optional per-channel vector added to x BEFORE the statistics (deferred biases)
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int iv = sub + v * LPR;
     const bool ok = iv < nvec;
     gm[v] = ok ? *reinterpret_cast<const f32x4*>(gamma + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
     bt[v] = ok ? *reinterpret_cast<const f32x4*>(beta + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
+    pb[v] = (ok && pre) ? *reinterpret_cast<const f32x4*>(pre + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float inv_c = 1.0f / (float)C;
   for (long long r0 = wave_id * RPW; r0 < rows; r0 += nwave * RPW) {
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int iv = sub + v * LPR;
-      xv[v] = (live && iv < nvec) ? *reinterpret_cast<const f32x4*>(x + row * C + 4 * iv) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xv[v] = (live && iv < nvec) ? *reinterpret_cast<const f32x4*>(x + row * C + 4 * iv) + pb[v] : f32x4{0.f, 0.f, 0.f, 0.f};
       s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
     }
 #pragma unroll
@@ -71,14 +73,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 template <int LPR, int NV>
-static int32_t launch(const float* x, const float* g, const float* b, float* y, long long rows, int C, float eps,
-                      hipStream_t s) {
+static int32_t launch(const float* x, const float* pre, const float* g, const float* b, float* y, long long rows, int C,
+                      float eps, hipStream_t s) {
   constexpr int RPW = 64 / LPR;
   long long waves = (rows + RPW - 1) / RPW;
   long long blocks = (waves + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((layernorm_kernel<LPR, NV>), dim3((unsigned)blocks), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+  hipLaunchKernelGGL((layernorm_kernel<LPR, NV>), dim3((unsigned)blocks), dim3(256), 0, s, x, pre, g, b, y, rows, C, eps);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
@@ -88,25 +90,30 @@ static int32_t launch(const float* x, const float* g, const float* b, float* y, 
 
 using namespace dlwp;
 
-extern "C" int32_t dlwp_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
-                                      int32_t channels, float eps, void* stream) {
+extern "C" int32_t dlwp_layernorm_prebias_f32(const float* x, const float* pre, const float* gamma, const float* beta,
+                                              float* y, int64_t rows, int32_t channels, float eps, void* stream) {
   DLWP_REQUIRE(x && gamma && beta && y, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(rows > 0 && channels > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
   DLWP_REQUIRE(channels % 4 == 0 && channels <= 2048, DLWP_ERR_UNSUPPORTED,
                "channels %d: must be a multiple of 4 and <= 2048", channels);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nvec = channels / 4;
-  if (nvec <= 16) return norm::launch<16, 1>(x, gamma, beta, y, rows, channels, eps, s);
-  if (nvec <= 32) return norm::launch<32, 1>(x, gamma, beta, y, rows, channels, eps, s);
+  if (nvec <= 16) return norm::launch<16, 1>(x, pre, gamma, beta, y, rows, channels, eps, s);
+  if (nvec <= 32) return norm::launch<32, 1>(x, pre, gamma, beta, y, rows, channels, eps, s);
   const int nv = (nvec + 63) / 64;
   switch (nv) {
-    case 1: return norm::launch<64, 1>(x, gamma, beta, y, rows, channels, eps, s);
-    case 2: return norm::launch<64, 2>(x, gamma, beta, y, rows, channels, eps, s);
-    case 3: return norm::launch<64, 3>(x, gamma, beta, y, rows, channels, eps, s);
-    case 4: return norm::launch<64, 4>(x, gamma, beta, y, rows, channels, eps, s);
-    case 5: case 6: return norm::launch<64, 6>(x, gamma, beta, y, rows, channels, eps, s);
-    default: return norm::launch<64, 8>(x, gamma, beta, y, rows, channels, eps, s);
+    case 1: return norm::launch<64, 1>(x, pre, gamma, beta, y, rows, channels, eps, s);
+    case 2: return norm::launch<64, 2>(x, pre, gamma, beta, y, rows, channels, eps, s);
+    case 3: return norm::launch<64, 3>(x, pre, gamma, beta, y, rows, channels, eps, s);
+    case 4: return norm::launch<64, 4>(x, pre, gamma, beta, y, rows, channels, eps, s);
+    case 5: case 6: return norm::launch<64, 6>(x, pre, gamma, beta, y, rows, channels, eps, s);
+    default: return norm::launch<64, 8>(x, pre, gamma, beta, y, rows, channels, eps, s);
   }
+}
+
+extern "C" int32_t dlwp_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
+                                      int32_t channels, float eps, void* stream) {
+  return dlwp_layernorm_prebias_f32(x, nullptr, gamma, beta, y, rows, channels, eps, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

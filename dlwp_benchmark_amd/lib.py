@@ -83,6 +83,8 @@ SIGNATURES = {
     "dlwp_convlstm_gates_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]),
     "dlwp_layernorm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_float, c_void_p]),
+    "dlwp_layernorm_prebias_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_float,
+                                             c_void_p]),
     "dlwp_layernorm_nhwc_to_nchw_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64, c_int32,
                                                   c_float, c_void_p]),
     "dlwp_afno_merge_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

@@ -100,7 +100,8 @@ class _EarthSpecificBlock(nn.Module):
         self.register_buffer("attn_mask", _shift_mask(self.pad_resolution, self.window_size, self.shift_size)
                              if self.roll else None)
 
-    def forward(self, x):
+    def forward(self, x, pend=None):
+        """x holds (true x - pend); returns (x, pend) in the same convention."""
         ppl, plat, plon = self.pad_resolution
         wpl, wlat, wlon = self.window_size
         spl, slat, slon = self.shift_size
@@ -116,11 +117,20 @@ class _EarthSpecificBlock(nn.Module):
             mask_b1=(ppl - wpl, plat - wlat, plon + slon - wlon) if self.roll else (ops.BIG,) * 3,
             mask_b2=(ppl - spl, plat - slat, plon) if self.roll else (ops.BIG,) * 3,
             bias_mode=1, heads=self.num_heads, head_dim=self.dim // self.num_heads, scale=self.attn.scale)
-        qkv = self.attn.qkv(self.norm1(x))
+        if not x.is_contiguous():
+            if pend is not None:
+                x = x + pend
+            qkv = self.attn.qkv(self.norm1(x))
+            a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec,
+                                     precision=self.attention_precision)
+            x = x + self.attn.proj(a)
+            return x + self.mlp(self.norm2(x)), None
+        # residual adds as GEMM accumulation in place on x, Linear biases deferred into `pend` (ops.residual_block_tail)
+        qkv = self.attn.qkv(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre_bias=pend))
         a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec,
                                  precision=self.attention_precision)
-        x = x + self.attn.proj(a)
-        return x + self.mlp(self.norm2(x))
+        pend = ops.residual_block_tail(x, pend, a, self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2)
+        return x, pend
 
 
 class _BasicLayer(nn.Module):
@@ -131,8 +141,11 @@ class _BasicLayer(nn.Module):
             for i in range(depth)])
 
     def forward(self, x):
+        pend = None
         for blk in self.blocks:
-            x = blk(x)
+            x, pend = blk(x, pend)
+        if pend is not None:
+            x.add_(pend)   # the layer's deferred Linear biases, once
         return x
 
 

@@ -65,7 +65,8 @@ class _Block(nn.Module):
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self.attention_precision = "fp32"
 
-    def forward(self, x, h, w):
+    def forward(self, x, h, w, pend=None):
+        """x holds (true x - pend); returns (x, pend) in the same convention (pend None = nothing pending)."""
         wh, ww = self.window_size
         if h % wh or w % ww:
             raise _lib.DlwpError("feature map is not a multiple of the window: the reference pads with swapped axes "
@@ -78,11 +79,21 @@ class _Block(nn.Module):
             # region ids from the slices of swin_transformer.py:385-390 (shift = window // 2 there)
             mask_b1=(ops.BIG, h - wh, w - ww), mask_b2=(ops.BIG, h - wh // 2, w - ww // 2),
             bias_mode=0, heads=self.num_heads, head_dim=self.dim // self.num_heads, scale=self.attn.scale)
-        qkv = self.attn.qkv(self.norm1(x))
+        deferred = isinstance(self.norm1, ops.HipLayerNorm) and isinstance(self.norm2, ops.HipLayerNorm) and x.is_contiguous()
+        if not deferred:
+            if pend is not None:
+                x = x + pend
+            qkv = self.attn.qkv(self.norm1(x))
+            a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.relative_position_bias_table, spec,
+                                     precision=self.attention_precision)
+            x = x + self.attn.proj(a)
+            return x + self.mlp(self.norm2(x)), None
+        # residual adds as GEMM accumulation in place on x, Linear biases deferred into `pend` (ops.residual_block_tail)
+        qkv = self.attn.qkv(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre_bias=pend))
         a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.relative_position_bias_table, spec,
                                  precision=self.attention_precision)
-        x = x + self.attn.proj(a)
-        return x + self.mlp(self.norm2(x))
+        pend = ops.residual_block_tail(x, pend, a, self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2)
+        return x, pend
 
 
 class _PatchMerging(nn.Module):
@@ -111,8 +122,11 @@ class _BasicLayer(nn.Module):
         self.downsample = _PatchMerging(dim, norm_layer) if downsample else None
 
     def forward(self, x, h, w):
+        pend = None
         for blk in self.blocks:
-            x = blk(x, h, w)
+            x, pend = blk(x, h, w, pend)
+        if pend is not None:
+            x.add_(pend)   # the layer's deferred Linear biases, once
         if self.downsample is not None:
             return x, self.downsample(x, h, w), (h + 1) // 2, (w + 1) // 2
         return x, x, h, w

@@ -404,8 +404,9 @@ def afno_block_tail(f_cf: torch.Tensor, l_cf: torch.Tensor, x_nhwc: torch.Tensor
     return (out, nxt) if emit_norm is not None else out
 
 
-def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """LayerNorm over the last dimension (any leading shape)."""
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
+               pre_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm over the last dimension (any leading shape); pre_bias [C] is added to x before the statistics."""
     _lib.require_cuda_tensor(x, "x")
     x = x.contiguous()
     c = x.shape[-1]
@@ -413,9 +414,29 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     y = torch.empty_like(x)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        _lib.check(lib.dlwp_layernorm_f32(x.data_ptr(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
-                                          y.data_ptr(), rows, c, float(eps), _lib.stream_ptr()), "dlwp_layernorm_f32")
+        _lib.check(lib.dlwp_layernorm_prebias_f32(x.data_ptr(), pre_bias.contiguous().data_ptr() if pre_bias is not None else None,
+                                                  weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                                                  y.data_ptr(), rows, c, float(eps), _lib.stream_ptr()),
+                   "dlwp_layernorm_prebias_f32")
     return y
+
+
+def residual_block_tail(x: torch.Tensor, pend: Optional[torch.Tensor], attn_out: torch.Tensor, proj: torch.nn.Linear,
+                        norm2: torch.nn.LayerNorm, fc1: torch.nn.Linear, fc2: torch.nn.Linear):
+    """`x = x + proj(attn_out); x = x + fc2(gelu(fc1(norm2(x))))` of a Swin / Pangu block (swin_transformer.py:254-262,
+    panguweather.py:318-322) with both residual adds as the beta = 1 accumulation of the GEMMs, IN PLACE on x, and
+    the Linear biases deferred: x holds (true x - pend); returns the new pend.  The caller adds pend once per layer."""
+    c = x.shape[-1]
+    x2 = x.view(-1, c)
+    x2.addmm_(attn_out.reshape(-1, c), proj.weight.t())
+    if proj.bias is not None:
+        pend = proj.bias if pend is None else pend + proj.bias
+    n2 = layer_norm(x, norm2.weight, norm2.bias, norm2.eps, pre_bias=pend)
+    hid = torch.nn.functional.gelu(torch.nn.functional.linear(n2, fc1.weight, fc1.bias))
+    x2.addmm_(hid.view(-1, hid.shape[-1]), fc2.weight.t())
+    if fc2.bias is not None:
+        pend = fc2.bias if pend is None else pend + fc2.bias
+    return pend
 
 
 class HipLayerNorm(torch.nn.LayerNorm):

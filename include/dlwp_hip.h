@@ -284,6 +284,13 @@ int32_t dlwp_convlstm_gates_f32(const float* gates_dev, const float* c_prev_dev,
  * swin_transformer.py:213,262,304,440,664, models/panguweather/panguweather.py:73,127,281,321. */
 int32_t dlwp_layernorm_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
                            int64_t rows, int32_t channels, float eps, void* stream);
+/* y = LayerNorm(x + pre_bias): pre_bias_dev [channels] (or NULL) is added before the statistics.  Lets the transformer
+ * blocks (swin_transformer.py:254-262, panguweather.py:318-322: `x = shortcut + proj(attn)`, `x = x + mlp(norm2(x))`) run
+ * their residual adds as the beta = 1 accumulation of the proj / fc2 GEMMs, in place on x, with the Linear biases
+ * carried as ONE pending per-channel vector that only the LayerNorms (here) and the end of the layer ever apply. */
+int32_t dlwp_layernorm_prebias_f32(const float* x_dev, const float* pre_bias_dev, const float* gamma_dev,
+                                   const float* beta_dev, float* y_dev, int64_t rows, int32_t channels, float eps,
+                                   void* stream);
 
 /* FourCastNet block glue fused with the layout change the FFT needs (models/fourcastnet/fourcastnet.py
  * :180-193 around AFNO2D :78-127).  x is token-major [B, tokens, C] ("NHWC"), y / f / l channel-major
