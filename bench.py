@@ -119,8 +119,8 @@ def cpu_baseline(state_dict, prog_cpu, rollout_steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="initial conditions per GPU")
     ap.add_argument("--rollout-steps", type=int, default=20)
     ap.add_argument("--cpu-batch", type=int, default=8, help="samples of the bounded CPU-baseline leg")
@@ -171,21 +171,34 @@ def main():
     scorer = RolloutMetrics(torch.zeros(H))
     target = prog[:, model.context_size:].contiguous()
     scores = {}
+    acc = {"sums": None, "samples": 0}
 
     def step():
         out = runner(prognostic=prog)
         if args.collect == "metrics":
-            scores["last"] = scorer(out, target, world_size=world)   # sums kernel (+ all-reduce when world > 1)
+            # this rank's squared-error sums of the rollout, ADDED to the evaluation's running sums on the device (the
+            # reference accumulates over all batches before taking the root, evaluate.py:786-821): no collective per step
+            s = scorer.sums(out, target)
+            acc["sums"] = s if acc["sums"] is None else acc["sums"].add_(s)
+            acc["samples"] += B
         return out
+
+    def finish():
+        # the ONE collective of the sharded evaluation: all-reduce of [4, K, C] sums + sample count (inside the timed region)
+        if args.collect == "metrics" and acc["sums"] is not None:
+            scores["last"] = scorer.finalize(acc["sums"], float(acc["samples"]), H * W, world_size=world)
 
     for _ in range(args.warmup):
         out = step()
+    finish()                      # also initialises the communicator's all-reduce path before the clock starts
+    acc["sums"], acc["samples"] = None, 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    finish()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -213,7 +226,7 @@ def main():
         "config": {
             "workload": "FNO2d modes=12 hidden=32 lift/proj=256 layers=4, Navier-Stokes 64x64, 20-step rollout, fp32 (BASELINE configs[1])",
             "batch_per_gpu": B, "global_batch": B * world, "grid": [H, W], "rollout_steps": K_roll,
-            "parallelism": (f"batch-shard x{world}, " + {"metrics": "all-reduce of on-device RMSE sums",
+            "parallelism": (f"batch-shard x{world}, " + {"metrics": "on-device RMSE sums accumulated per rank, one all-reduce per evaluation",
                                                           "gather": "chunked all-gather of trajectories",
                                                           "none": "no collective"}[args.collect])
             if world > 1 else "single GPU",

@@ -59,21 +59,27 @@ class RolloutMetrics:
 
     def __call__(self, out: torch.Tensor, target: torch.Tensor, world_size: int = 1):
         """Returns {"rmse": [K, C], "acc": [K, C] or None} over ALL ranks' samples."""
-        s = self.sums(out, target)
-        n_samples = float(out.shape[0])
+        return self.finalize(self.sums(out, target), float(out.shape[0]), out.shape[-2] * out.shape[-1], world_size)
+
+    def finalize(self, s: torch.Tensor, n_samples: float, cells: int, world_size: int = 1):
+        """Scores from accumulated sums: `s` = this rank's [4, K, C] sums (of one batch, or ADDED UP over many -- the
+        reference accumulates squared errors over the whole evaluation before taking the root, evaluate.py:786-821),
+        n_samples = how many samples went into them, cells = H * W.  With world_size > 1 ONE all-reduce moves the sums
+        and the sample count (shards may differ in size): the only collective of a sharded evaluation."""
         if world_size > 1:
             import torch.distributed as dist
 
             host = dist.get_backend(self.group) != "nccl"
-            buf = torch.empty(s.numel() + 1, dtype=torch.float64, device=out.device)
+            dev = s.device
+            buf = torch.empty(s.numel() + 1, dtype=torch.float64, device=dev)
             buf[:-1].copy_(s.flatten())
-            buf[-1:].fill_(n_samples)   # shards may differ by one sample: the count travels with the sums
+            buf[-1:].fill_(n_samples)   # the count travels with the sums
             if host:
                 buf = buf.cpu()
             dist.all_reduce(buf, group=self.group)
-            buf = buf.to(out.device)
+            buf = buf.to(dev)
             s, n_samples = buf[:-1].view_as(s), buf[-1:]
-        count = n_samples * out.shape[-2] * out.shape[-1]
+        count = n_samples * cells
         rmse = torch.sqrt(s[0] / count)
         acc = s[1] / torch.sqrt(s[2] * s[3]) if self.clim is not None else None
         return {"rmse": rmse, "acc": acc}
