@@ -101,19 +101,225 @@ def profile_kernels(model, prog, repeats):
     return {names[i]: (max(tot[i] / max(n[i], 1) - 0.5 * empty, 0.0), n[i] // repeats) for i in range(4)}, empty
 
 
-def cpu_baseline(state_dict, prog_cpu, rollout_steps):
-    """Times the oracle on the host cores; returns (cell-steps/s, seconds, trajectory)."""
+def cpu_baseline(state_dict, prog_cpu, rollout_steps, timed=3):
+    """Times the oracle on the host cores (BASELINE.md section 3: 1 warm-up rollout + `timed` timed rollouts, median);
+    returns (cell-steps/s, median seconds, all seconds, trajectory)."""
     from oracle.restate.fno import FNO2DModuleRef  # checker / reported baseline only
 
     ref = FNO2DModuleRef(**MODEL_KW).eval()
     ref.load_state_dict(state_dict)
+    secs = []
     with torch.no_grad():
-        ref(prognostic=prog_cpu[:, :2])  # warm-up: one step
-        t0 = time.perf_counter()
-        traj = ref(prognostic=prog_cpu)
-        dt = time.perf_counter() - t0
+        traj = ref(prognostic=prog_cpu)  # warm-up: one whole rollout (also the parity trajectory)
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            ref(prognostic=prog_cpu)
+            secs.append(time.perf_counter() - t0)
+    med = sorted(secs)[len(secs) // 2]
     b, _, _, h, w = prog_cpu.shape
-    return b * h * w * rollout_steps / dt, dt, traj
+    return b * h * w * rollout_steps / med, med, secs, traj
+
+
+MFMA_BF16_PEAK_TF = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+
+
+def other_config_table():
+    """The BASELINE configs that are NOT the headline line (C1, C3, C4, C5) at their BASELINE sizes:
+    tag -> (class name, ctor kwargs, batch per GPU, rollout steps, (H, W), golden fixture of the same architecture + filler weights)."""
+    return {
+        "C1_unet_64x64": ("UNet", dict(constant_channels=0, prescribed_channels=0, prognostic_channels=1,
+                                       hidden_channels=[8, 16, 32, 64], n_convolutions=2, activation="th.nn.GELU()",
+                                       context_size=1), 32, 1, (64, 64), "unet_c1_64x64", 1.0),
+        "C3_swin_32x64": ("SwinTransformer", dict(context_size=1, img_height=32, img_width=64, patch_size=1, constant_channels=4,
+                                                  prescribed_channels=1, prognostic_channels=3, embed_dim=96, depths=[4, 4],
+                                                  num_heads=[4, 4], mlp_ratio=4, qkv_bias=True, drop_path_rate=0.2,
+                                                  norm_layer="nn.LayerNorm", patch_norm=True), 32, 12, (32, 64), "swin_c3_full", 0.7),
+        "C4_fourcastnet_128x256": ("FourCastNet", dict(img_height=128, img_width=256, patch_size=[1, 1], constant_channels=4,
+                                                       prescribed_channels=1, prognostic_channels=3, filter="AFNO2D",
+                                                       embed_dim=64, depth=4, mlp_ratio=4.0, num_blocks=4,
+                                                       sparsity_threshold=0.01, hard_thresholding_fraction=1.0,
+                                                       context_size=1, use_pos_embed=True), 32, 20, (128, 256), "afno_c4_full", 0.7),
+        "C5_pangu_128x256x13": ("PanguWeather", dict(constant_channels=4, prescribed_channels=1, prognostic_channels=13,
+                                                     embed_dim=192, num_heads=[6, 12, 12, 6], window_size=[2, 6, 12],
+                                                     patch_size=[1, 1], n_lat=128, n_lon=256, context_size=1), 8, 5, (128, 256),
+                                "pangu_c5_full", 0.7),
+    }
+
+
+def _golden_inputs(cfg, batch, frames):
+    """the seeded inputs the committed fixtures were made with (oracle/make_golden.py:model_inputs, seed 4321) --
+    restated here because bench.py's GPU legs may not import anything under oracle/."""
+    from dlwp_benchmark_amd.synthetic import navier_stokes, weatherbench
+
+    h = cfg.get("img_height", cfg.get("n_lat", 64))
+    w = cfg.get("img_width", cfg.get("n_lon", 64))
+    if cfg["constant_channels"] == 0 and cfg["prescribed_channels"] == 0:
+        return navier_stokes(batch, frames, h, w, channels=cfg["prognostic_channels"], seed=4321)
+    return weatherbench(batch, frames, h, w, prognostic_channels=cfg["prognostic_channels"],
+                        constant_channels=cfg["constant_channels"], prescribed_channels=cfg["prescribed_channels"], seed=4321)
+
+
+def _attn_tag(name, a):
+    if name.startswith("dlwp_window_attn"):
+        d = a[0]._obj
+        return (tuple(d.padded), tuple(d.window), int(d.heads), int(d.head_dim), int(a[5]), int(d.use_mask))
+    return None
+
+
+def _attn_flops(tag):
+    """4 * B * nW * nH * N^2 * d (QK^T + PV, padding tokens included as the reference computes them)."""
+    padded, window, heads, hd, batch, _ = tag
+    n = window[0] * window[1] * window[2]
+    nw = (padded[0] // window[0]) * (padded[1] // window[1]) * (padded[2] // window[2])
+    return 4.0 * batch * nw * heads * n * n * hd
+
+
+def bench_other_configs(device, only=None, reps=2):
+    """C1 / C3 / C4 / C5 through the HIP path on this GPU: whole-rollout wall time (inputs resident), per-step rel-L2
+    of the SAME architecture + filler weights against the committed fixture of the real reference classes
+    (tests/golden/model_*_full.npz: one initial condition, two steps), and a roofline for the dominant hand-written
+    kernel from ALGORITHMIC flops / bytes / HIP-event time / the peak of the pipe it runs on."""
+    import numpy as np
+
+    import dlwp_benchmark_amd.models as M
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.synthetic import navier_stokes, weatherbench
+    from dlwp_benchmark_amd.weights import fill_state_dict
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    res = {}
+    for tag, (cls, cfg, batch, steps, (h, w), gold, gain) in other_config_table().items():
+        if only and tag not in only:
+            continue
+        variants = ["fp32"] + (["bf16"] if cls in ("SwinTransformer", "PanguWeather") else [])
+        model = getattr(M, cls)(**cfg)
+        sha = fill_state_dict(model, gain=gain)
+        model = model.to(device).eval()
+        if cfg["constant_channels"] == 0:
+            c, p, g = navier_stokes(batch, steps + 1, h, w, channels=cfg["prognostic_channels"])
+        else:
+            c, p, g = weatherbench(batch, steps + 1, h, w, prognostic_channels=cfg["prognostic_channels"])
+        dev = lambda t: t.to(device) if t is not None else None
+        c, p, g = dev(c), dev(p), dev(g)
+        gpath = os.path.join(gdir, f"model_{gold}.npz")
+        want = None
+        if os.path.exists(gpath):
+            gz = np.load(gpath, allow_pickle=False)
+            if str(gz["sha"]) == sha:
+                want = torch.from_numpy(gz["y"])
+        for prec in variants:
+            if hasattr(model, "set_attention_precision"):
+                model.set_attention_precision(prec)
+            entry = {"workload": f"{cls} {h}x{w}, {cfg['prognostic_channels']} prognostic ch, {steps}-step rollout, "
+                                 f"{'bf16 window attention (fp32 elsewhere)' if prec == 'bf16' else 'fp32'}",
+                     "batch": batch, "rollout_steps": steps, "weights": "deterministic filler sha256:" + sha[:16]}
+            out = model(constants=c, prescribed=p, prognostic=g)      # warm-up (plans, allocator)
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                out = model(constants=c, prescribed=p, prognostic=g)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            dt = sorted(times)[len(times) // 2] if len(times) % 2 else min(times)
+            entry.update(ms_per_rollout=dt * 1e3, ms_per_step=dt * 1e3 / steps,
+                         cell_steps_per_s=batch * h * w * steps / dt, finite=bool(torch.isfinite(out).all()))
+            # parity of this architecture + these weights against the committed reference trajectory
+            if want is not None:
+                frames = want.shape[1] + cfg["context_size"]
+                gc, gp, gg = _golden_inputs(cfg, want.shape[0], frames)
+                got = model(constants=dev(gc), prescribed=dev(gp), prognostic=dev(gg)).cpu().double()
+                wd = want.double()
+                errs = [float(torch.linalg.vector_norm(got[:, t] - wd[:, t]) / torch.linalg.vector_norm(wd[:, t]))
+                        for t in range(wd.shape[1])]
+                entry["rel_l2_per_step_vs_golden"] = [float(f"{e:.3e}") for e in errs]
+                entry["golden"] = f"tests/golden/model_{gold}.npz (real reference class, {want.shape[0]} sample, {want.shape[1]} steps)"
+                entry["rel_l2_bound"] = 5e-3 if prec == "bf16" else 1e-5
+                entry["parity_ok"] = max(errs) <= entry["rel_l2_bound"]
+            # per-entry-point event timing of one more rollout
+            with L.KernelTimer(tagger=_attn_tag) as kt:
+                model(constants=c, prescribed=p, prognostic=g)
+            summ, marker = kt.summary()
+            covered = sum(v["total_ms"] for v in summ.values())
+            by_name = {}
+            for (name, _), v in summ.items():
+                d = by_name.setdefault(name, {"calls": 0, "total_ms": 0.0})
+                d["calls"] += v["calls"]
+                d["total_ms"] += v["total_ms"]
+            entry["hip_entry_points_ms_per_rollout"] = {k: round(v["total_ms"], 4) for k, v in
+                                                        sorted(by_name.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}
+            entry["share_outside_libdlwp_hip"] = max(0.0, 1.0 - covered / (dt * 1e3))   # rocBLAS / MIOpen / torch glue
+            entry["roofline"] = _other_roofline(cls, cfg, batch, h, w, summ, prec)
+            res[tag if prec == "fp32" else tag + "_bf16attn"] = entry
+        del model, out
+        torch.cuda.empty_cache()
+    return res
+
+
+def _other_roofline(cls, cfg, batch, h, w, summ, prec):
+    """roofline of the config's dominant hand-written kernel: algorithmic work per launch / event time."""
+    if cls in ("SwinTransformer", "PanguWeather"):
+        attn = {k: v for k, v in summ.items() if k[0].startswith("dlwp_window_attn")}
+        if not attn:
+            return None
+        (name, tag), v = max(attn.items(), key=lambda kv: kv[1]["total_ms"])   # the shape class that costs most
+        fl = _attn_flops(tag)
+        peak = MFMA_BF16_PEAK_TF if prec == "bf16" else MFMA_F32_PEAK_TF
+        ach = fl / (v["avg_ms"] * 1e-3) / 1e12
+        return {"kernel": f"window_attn_kernel via {name} (window {tag[1]}, {tag[2]} heads x {tag[3]}, B={tag[4]}, "
+                          f"{'shifted+masked' if tag[5] else 'unshifted'})",
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "algorithmic_flops_per_launch": fl, "avg_launch_ms": v["avg_ms"], "launches_per_rollout": v["calls"],
+                "pipe": "bf16 MFMA (dense peak)" if prec == "bf16" else "fp32-accurate form priced against the fp32 matrix peak"}
+    if cls == "FourCastNet":
+        c, hid = cfg["embed_dim"], int(cfg["embed_dim"] * cfg["mlp_ratio"])
+        tail = [(k, v) for k, v in summ.items() if k[0] in ("dlwp_afno_block_tail_f32", "dlwp_token_mlp_f32", "dlwp_token_mlp_emit_norm_f32")]
+        if not tail:
+            return None
+        tot = sum(v["total_ms"] for _, v in tail)
+        n = sum(v["calls"] for _, v in tail)
+        avg = tot / n
+        tokens = batch * h * w
+        fl = 4.0 * tokens * c * hid                      # fc1 + fc2
+        by = 4.0 * tokens * c * 4                        # f, l, x read + x written (SURVEY 8d: one read + one write per operand plane)
+        ach = by / (avg * 1e-3) / 1e9
+        return {"kernel": "token_mlp_kernel<MERGE, NEXT> via dlwp_afno_block_tail_f32 (irfft out + skips + LN2 + fc1/GELU/fc2 + next LN1)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": by, "avg_launch_ms": avg, "launches_per_rollout": n,
+                "mfma_view": {"algorithmic_flops_per_launch": fl, "achieved_TFLOPs": fl / (avg * 1e-3) / 1e12,
+                              "frac_of_f32_matrix_peak": fl / (avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF},
+                "step_hbm_view": "whole step: SURVEY 8d counts 128 MiB/sample-step; see ms_per_step"}
+    if cls == "UNet":
+        conv = [(k, v) for k, v in summ.items() if k[0] == "dlwp_conv3x3_cyl_f32"]
+        if not conv:
+            return None
+        tot = sum(v["total_ms"] for _, v in conv)
+        n = sum(v["calls"] for _, v in conv)
+        return {"kernel": "conv3x3_cyl_kernel via dlwp_conv3x3_cyl_f32 (all levels)", "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": tot / n, "launches_per_rollout": n,
+                "note": "64x64 maps: every launch is a few microseconds -- launch/latency-bound, no meaningful byte roofline"}
+    return None
+
+
+def host_threads():
+    """threads for the CPU-baseline leg = the cores this process may actually use: the cgroup CPU quota when one is
+    set (a quota is CPU time, so that many threads land on distinct physical cores of a larger machine), otherwise
+    the affinity mask divided by the hardware threads per core."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    smt = 1
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = max(1, len(sib.replace("-", ",").split(",")))
+    except Exception:
+        pass
+    phys = max(1, n // smt)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, min(phys, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        pass
+    return phys
 
 
 def main():
@@ -123,8 +329,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="initial conditions per GPU")
     ap.add_argument("--rollout-steps", type=int, default=20)
-    ap.add_argument("--cpu-batch", type=int, default=8, help="samples of the bounded CPU-baseline leg")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="samples of the bounded CPU-baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU-baseline leg (0 = usable physical cores)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C1/C3/C4/C5 legs")
+    ap.add_argument("--only-configs", nargs="*", help="subset of the other-config tags")
     ap.add_argument("--gather-chunks", type=int, default=4)
     ap.add_argument("--collect", choices=["metrics", "gather", "none"], default="metrics",
                     help="what leaves a rank per rollout: per-lead-time RMSE sums reduced on the device and all-reduced "
@@ -318,18 +527,31 @@ def main():
         if not args.no_cpu_baseline:
             nb = min(args.cpu_batch, B)
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            cps, secs, traj = cpu_baseline(sd, prog_cpu[:nb].contiguous(), K_roll)
+            nthreads = args.cpu_threads or host_threads()
+            torch.set_num_threads(nthreads)
+            cps, med, secs, traj = cpu_baseline(sd, prog_cpu[:nb].contiguous(), K_roll)
             got = out[:nb].detach().cpu().double()
             want = traj.double()
             errs = [float(torch.linalg.vector_norm(got[:, t] - want[:, t]) / torch.linalg.vector_norm(want[:, t]))
                     for t in range(K_roll)]
             result["cpu_baseline"] = {
-                "value": cps, "unit": "grid-cells*steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                "value": cps, "unit": "grid-cells*steps/s", "cores": nthreads, "kind": "port",
                 "sample": f"oracle (PyTorch {torch.__version__} CPU restatement) on {nb} of the {B} initial conditions, "
-                          f"{K_roll} steps, {secs:.2f} s",
+                          f"{K_roll} steps; 1 warm-up + {len(secs)} timed rollouts, median {med:.2f} s "
+                          f"(all: {', '.join('%.2f' % x for x in secs)}); {nthreads} threads = usable physical cores "
+                          f"(os.cpu_count() {os.cpu_count()})",
             }
             result["rel_l2_per_step_max"] = max(errs)
             result["rel_l2_per_step"] = [float(f"{e:.3e}") for e in errs]
+            if max(errs) > 1e-5:
+                result["parity_ok"] = False
+
+        # ---- the other BASELINE configs (C1, C3, C4, C5) through the HIP path, same process, same GPU
+        if not args.no_other_configs:
+            try:
+                result["other_configs"] = bench_other_configs(device, only=args.only_configs)
+            except Exception as e:   # the headline line must survive a failure here; the failure is reported, not hidden
+                result["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         print(json.dumps(result))

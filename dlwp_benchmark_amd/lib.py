@@ -157,3 +157,65 @@ def stream_ptr():
     import torch
 
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KernelTimer:
+    """Measurement aid (bench.py): brackets every call of the chosen C-ABI entry points with HIP events on the stream
+    the call launches on (torch's current stream = the `stream` argument every wrapper passes) and sums the elapsed
+    time per (entry point, tag).  `tagger(name, args) -> hashable` separates calls of one entry point by shape.
+    An EMPTY bracket is recorded beside every call; half of its mean (one marker latency) is subtracted per call,
+    which reproduces rocprofv3 --kernel-trace averages within a few per cent (bench.py).
+    The product path never uses this class."""
+
+    def __init__(self, names=None, tagger=None):
+        self.names = names
+        self.tagger = tagger
+        self.records = []
+        self._empty = []
+        self._saved = {}
+
+    def __enter__(self):
+        import torch
+
+        lib = load()
+        names = self.names or [n for n in SIGNATURES if n.endswith(("_f32", "_bf16"))]
+        for name in names:
+            fn = getattr(lib, name)
+            self._saved[name] = fn
+
+            def wrapped(*a, _fn=fn, _name=name):
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+                rc = _fn(*a)
+                e1.record()
+                e2.record()
+                self.records.append((_name, self.tagger(_name, a) if self.tagger else None, e0, e1))
+                self._empty.append((e1, e2))
+                return rc
+
+            setattr(lib, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for name, fn in self._saved.items():
+            setattr(lib, name, fn)
+        self._saved = {}
+        return False
+
+    def summary(self):
+        """{(name, tag): {"calls": n, "total_ms": t, "avg_ms": t / n}} after a device synchronisation."""
+        import torch
+
+        torch.cuda.synchronize()
+        marker = 0.0
+        if self._empty:
+            marker = 0.5 * sum(a.elapsed_time(b) for a, b in self._empty) / len(self._empty)
+        out = {}
+        for name, tag, e0, e1 in self.records:
+            d = out.setdefault((name, tag), {"calls": 0, "total_ms": 0.0})
+            d["calls"] += 1
+            d["total_ms"] += max(e0.elapsed_time(e1) - marker, 0.0)
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["calls"]
+        return out, marker

@@ -32,7 +32,10 @@ class HipBackbone(torch.nn.Module):
     def _step_fn(self):
         if not self.step_graphs or self.training:
             return self.one_step
-        key = tuple(p.data_ptr() for p in self.parameters())
+        # keyed on (version, pointer) of every parameter and buffer: load_state_dict / optimizer steps write IN PLACE
+        # (same pointers), and a captured graph bakes in derived buffers (packed MLP operands, plans) made from the
+        # old values -- a version bump re-captures, whose warm-up re-derives them
+        key = self._param_key()
         if self._graphed is None or self._graphed[0] != key:
             from ..graphs import GraphedStep
 
@@ -59,4 +62,4 @@ class HipBackbone(torch.nn.Module):
         return self._ws
 
     def _param_key(self):
-        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+        return tuple((p._version, p.data_ptr()) for p in list(self.parameters()) + list(self.buffers()))

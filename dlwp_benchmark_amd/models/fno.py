@@ -26,6 +26,74 @@ class _DenseComplexTensor(nn.Module):
         super().__init__()
         self.tensor = nn.Parameter(torch.zeros(*shape, dtype=torch.cfloat))
 
+    def dense(self) -> torch.Tensor:
+        return self.tensor
+
+
+def tucker_rank(shape, rank):
+    """Ranks of a Tucker factorisation holding `rank` (float) x the dense parameter count -- the rule the TFNO's
+    tensor library applies (tensorly `validate_tucker_rank`, rounding="round", no fixed modes): with x the common
+    fraction per mode, core + factors = prod(shape) x^n + sum(s_i^2) x = rank * prod(shape); rank_i = round(s_i x) >= 1.
+    An int or a list is taken as is."""
+    shape = [int(s) for s in shape]
+    if isinstance(rank, (list, tuple)):
+        return [int(r) for r in rank]
+    if isinstance(rank, int) and not isinstance(rank, bool):
+        return [min(int(rank), s) for s in shape]
+    rank = float(rank)
+    n = len(shape)
+    full = 1.0
+    for s_ in shape:
+        full *= s_
+    sq = float(sum(s_ * s_ for s_ in shape))
+    f = lambda x: full * x ** n + sq * x - rank * full
+    lo, hi = 0.0, max(rank, 1.0)
+    for _ in range(200):     # bisection (f is increasing on [0, hi], f(0) < 0 <= f(hi))
+        mid = 0.5 * (lo + hi)
+        if f(mid) > 0.0:
+            hi = mid
+        else:
+            lo = mid
+    x = 0.5 * (lo + hi)
+    return [max(int(round(s_ * x)), 1) for s_ in shape]
+
+
+class _FactorList(nn.Module):
+    def __init__(self, factors):
+        super().__init__()
+        for i, f in enumerate(factors):
+            self.register_parameter(f"factor_{i}", f)
+
+    def __iter__(self):
+        i = 0
+        while hasattr(self, f"factor_{i}"):
+            yield getattr(self, f"factor_{i}")
+            i += 1
+
+
+class _TuckerComplexTensor(nn.Module):
+    """Complex Tucker-factorised weight in the parameter layout of the TFNO's tensor library (tltorch
+    `ComplexTuckerTensor`): `core` [r_0, .., r_{n-1}, 2] and `factors.factor_i` [dim_i, r_i, 2], complex numbers
+    stored as trailing (re, im) pairs.  dense() = core x_0 F_0 x_1 F_1 ... (mode products)."""
+
+    def __init__(self, shape, rank):
+        super().__init__()
+        self.shape = tuple(int(s_) for s_ in shape)
+        self.rank = tuple(tucker_rank(self.shape, rank))
+        self.core = nn.Parameter(torch.zeros(*self.rank, 2))
+        self.factors = _FactorList([nn.Parameter(torch.zeros(d, r, 2)) for d, r in zip(self.shape, self.rank)])
+
+    def dense(self) -> torch.Tensor:
+        t = torch.view_as_complex(self.core.contiguous())
+        letters = "abcdefgh"[:len(self.shape)]
+        outl = "ijklmnop"[:len(self.shape)]
+        for n, f in enumerate(self.factors):
+            fc = torch.view_as_complex(f.contiguous())
+            src = letters[:n].translate(str.maketrans(letters[:n], outl[:n])) + letters[n:]
+            dst = src.replace(letters[n], outl[n])
+            t = torch.einsum(f"{src},{outl[n]}{letters[n]}->{dst}", t, fc)
+        return t
+
 
 class _ChannelMLP(nn.Module):
     """neuralop MLP(n_layers=2): 1x1 convs with GELU in between."""
@@ -36,26 +104,28 @@ class _ChannelMLP(nn.Module):
 
 
 class _SpectralConvs(nn.Module):
-    def __init__(self, channels, n_layers, mh, mw):
+    def __init__(self, channels, n_layers, mh, mw, tucker_rank_=None):
         super().__init__()
-        self.weight = nn.ModuleList([_DenseComplexTensor((channels, channels, mh, mw)) for _ in range(n_layers)])
+        shape = (channels, channels, mh, mw)
+        self.weight = nn.ModuleList([_DenseComplexTensor(shape) if tucker_rank_ is None else
+                                     _TuckerComplexTensor(shape, tucker_rank_) for _ in range(n_layers)])
         self.bias = nn.Parameter(torch.zeros(n_layers, channels, 1, 1))
 
 
 class _FNOBlocks(nn.Module):
-    def __init__(self, channels, n_layers, mh, mw):
+    def __init__(self, channels, n_layers, mh, mw, tucker_rank_=None):
         super().__init__()
-        self.convs = _SpectralConvs(channels, n_layers, mh, mw)
+        self.convs = _SpectralConvs(channels, n_layers, mh, mw, tucker_rank_)
         self.fno_skips = nn.ModuleList([nn.Conv2d(channels, channels, 1, bias=False) for _ in range(n_layers)])
 
 
 class _FNO(nn.Module):
     def __init__(self, n_modes, in_channels, hidden_channels, lifting_channels, projection_channels,
-                 out_channels, n_layers):
+                 out_channels, n_layers, tucker_rank_=None):
         super().__init__()
         self.n_modes = [int(m) for m in n_modes]
         self.lifting = _ChannelMLP(in_channels, lifting_channels, hidden_channels)
-        self.fno_blocks = _FNOBlocks(hidden_channels, n_layers, self.n_modes[0], self.n_modes[1] // 2 + 1)
+        self.fno_blocks = _FNOBlocks(hidden_channels, n_layers, self.n_modes[0], self.n_modes[1] // 2 + 1, tucker_rank_)
         self.projection = _ChannelMLP(hidden_channels, projection_channels, out_channels)
 
 
@@ -72,8 +142,17 @@ class FNO2DModule(HipBackbone):
     def __init__(self, n_modes: list = [12, 12], constant_channels: int = 4, prescribed_channels: int = 1,
                  prognostic_channels: int = 8, hidden_channels: int = 32, lifting_channels: int = 256,
                  projection_channels: int = 256, n_layers: int = 4, max_n_modes: int = None, bias: bool = True,
-                 context_size: int = 10, **kwargs):
+                 context_size: int = 10, _tucker_rank=None, **kwargs):
         super().__init__()
+        n_modes = [int(m) for m in n_modes]
+        if len(n_modes) != 2:
+            raise ValueError(f"n_modes must have two entries (2-D operator), got {n_modes}")
+        if max_n_modes is not None and [int(m) for m in (max_n_modes if hasattr(max_n_modes, "__len__") else
+                                                         [max_n_modes] * 2)] != n_modes:
+            # the library would allocate max_n_modes-sized weights and use the n_modes corner: not reproduced
+            raise NotImplementedError(f"max_n_modes={max_n_modes} != n_modes={n_modes} is not supported by the HIP path")
+        # `bias` is accepted and NOT forwarded, exactly like the reference constructor (fno.py:29, :38-47): the
+        # library's spectral-convolution bias stays at its default (present)
         self.context_size = int(context_size)
         self.constant_channels = int(constant_channels)
         self.prescribed_channels = int(prescribed_channels)
@@ -82,7 +161,7 @@ class FNO2DModule(HipBackbone):
         self.in_channels = int(in_channels)
         self.fno = _FNO(n_modes=list(n_modes), in_channels=in_channels, hidden_channels=hidden_channels,
                         lifting_channels=lifting_channels, projection_channels=projection_channels,
-                        out_channels=prognostic_channels, n_layers=n_layers)
+                        out_channels=prognostic_channels, n_layers=n_layers, tucker_rank_=_tucker_rank)
         self._plan = None
         self._plan_key = None
 
@@ -124,7 +203,7 @@ class FNO2DModule(HipBackbone):
         spec = (ctypes.c_void_p * L)()
         skip = (ctypes.c_void_p * L)()
         for l in range(L):
-            wl = torch.view_as_real(f.fno_blocks.convs.weight[l].tensor.detach().cpu().contiguous())
+            wl = torch.view_as_real(f.fno_blocks.convs.weight[l].dense().detach().cpu().contiguous())
             wl = wl[:, :, :n_rows, :n_cols].contiguous().to(torch.float32)
             spec[l] = ptr(wl)
             skip[l] = ptr(host(f.fno_blocks.fno_skips[l].weight).reshape(
@@ -219,7 +298,7 @@ class FNO2DModule(HipBackbone):
         hid = f.lifting.fcs[1](F.gelu(f.lifting.fcs[0](x_t)))
         n_layers = len(f.fno_blocks.fno_skips)
         for l in range(n_layers):
-            wl = torch.view_as_real(f.fno_blocks.convs.weight[l].tensor)[:, :, :len(op.rows_in), :op.n_cols]
+            wl = torch.view_as_real(f.fno_blocks.convs.weight[l].dense())[:, :, :len(op.rows_in), :op.n_cols]
             hid = T.spectral_conv(hid, wl, op) + f.fno_blocks.convs.bias[l] + f.fno_blocks.fno_skips[l](hid)
             if l < n_layers - 1:
                 hid = F.gelu(hid)
@@ -261,3 +340,24 @@ class FNO2DModule(HipBackbone):
             out = torch.empty(b, t - ctx, cg, h, w, device=prognostic.device, dtype=torch.float32)
             self.rollout_into(out, constants, prescribed, prognostic)
         return out
+
+
+class TFNO2DModule(FNO2DModule):
+    """Drop-in for reference models/fno/fno.py:109-146 -- the class `configs/model/fno.yaml:1` names.  The reference
+    builds `neuralop.models.TFNO(rank=rank)`: the FNO above with every spectral weight stored as a complex Tucker
+    factorisation (`fno_blocks.convs.weight.{l}.core` / `.factors.factor_{i}`, tensorly-torch layout).  Here the dense
+    weight is rebuilt from the factors when the plan is created (and whenever a factor changes: the plan is keyed on
+    parameter versions), then the whole FNO path runs unchanged; in training mode the reconstruction is part of the
+    autograd graph.  PARITY UNPINNED like FNO2DModule: both third-party libraries are absent from the reference tree
+    and from this image."""
+
+    def __init__(self, n_modes: list = [12, 12], constant_channels: int = 4, prescribed_channels: int = 1,
+                 prognostic_channels: int = 8, hidden_channels: int = 32, lifting_channels: int = 256,
+                 projection_channels: int = 256, n_layers: int = 4, max_n_modes: int = None, rank: float = 1.0,
+                 bias: bool = True, context_size: int = 10, **kwargs):
+        kwargs.pop("_tucker_rank", None)
+        super().__init__(n_modes=n_modes, constant_channels=constant_channels, prescribed_channels=prescribed_channels,
+                         prognostic_channels=prognostic_channels, hidden_channels=hidden_channels,
+                         lifting_channels=lifting_channels, projection_channels=projection_channels, n_layers=n_layers,
+                         max_n_modes=max_n_modes, bias=bias, context_size=context_size, _tucker_rank=rank, **kwargs)
+        self.rank = rank
