@@ -19,6 +19,7 @@
 //   i.e. one read and one write of the activation per layer; lifting and projection MLPs are one
 //   fused kernel each (hidden 256-wide activation never leaves registers).
 #include "common.hpp"
+#include <atomic>
 
 // GELU form per phase of the fused step kernel (A/B switch: -DDLWP_GELU8_LIFT=gelu_erf8_fma etc.)
 #ifndef DLWP_GELU8_LIFT
@@ -1166,9 +1167,13 @@ struct TrunkParams {
   float* r_out;            // out        [B, T - ctx, n_prog, H, W]
   int r_nconst, r_npresc, r_nprog, r_T, r_ctx, r_t0;   // first time index of this launch (ctx + step_begin)
   int n_steps;             // 0 / 1: one step described by in / out / resid
+  // hand-off bounds (plan knobs): polls of a counter barrier / re-loads of a flag-in-data block before the workgroup
+  // gives up; a workgroup that gives up poisons its outputs with NaN AND sets *fail_word (checked by the host)
+  int spin_limit, try_limit;
+  unsigned* fail_word;
 };
 
-__device__ __forceinline__ void trunk_group_barrier(unsigned* ctr, unsigned target, int* s_fail) {
+__device__ __forceinline__ void trunk_group_barrier(unsigned* ctr, unsigned target, int* s_fail, int spin_limit) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);   // this wave's sc1 stores have reached the coherence point
   __syncthreads();
@@ -1177,7 +1182,7 @@ __device__ __forceinline__ void trunk_group_barrier(unsigned* ctr, unsigned targ
     int spins = 0;
     while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 17)) {   // ~ 0.1 s: a peer workgroup never arrived; give up loudly, never hang
+      if (++spins > spin_limit) {   // default ~ 0.1 s: a peer workgroup never arrived; give up loudly, never hang
         *s_fail = 1;
         break;
       }
@@ -1193,12 +1198,12 @@ __device__ __forceinline__ void trunk_group_arrive(unsigned* ctr) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void trunk_group_wait(unsigned* ctr, unsigned target, int* s_fail) {
+__device__ __forceinline__ void trunk_group_wait(unsigned* ctr, unsigned target, int* s_fail, int spin_limit) {
   if (threadIdx.x == 0) {
     int spins = 0;
     while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 17)) {
+      if (++spins > spin_limit) {
         *s_fail = 1;
         break;
       }
@@ -1241,11 +1246,15 @@ __device__ __forceinline__ bool has_sentinel(const f32x4& v) {
   return __float_as_uint(v[0]) == kSentinel || __float_as_uint(v[1]) == kSentinel ||
          __float_as_uint(v[2]) == kSentinel || __float_as_uint(v[3]) == kSentinel;
 }
+// The closing `s_nop 1`: a 16-byte store reads its data registers late, and the compiler -- which sees the statement as one
+// opaque instruction -- may overwrite them in the very next instruction (cdna_hip_programming.md 5.7 item 1).  Found in
+// this file by tools/asm_hazard_check.py (rule C) in round 2: the re-arming sentinel stores were followed one wait state
+// later by a VALU write to one of the four data registers.
 __device__ __forceinline__ void st4_sc1(const float* base, unsigned off, const f32x4& v) {
-  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" : : "v"(off), "v"(v), "s"(base) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void st4_l2(const float* base, unsigned off, const f32x4& v) {   // stays in this XCD's L2
-  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 // Exchange stores of the flag-in-data protocol.  `fast` = every workgroup of the sample's group was FOUND to sit on the
 // same XCD (HW_REG_XCC_ID exchanged during the first layer): a plain store keeps the line in that XCD's L2, where the
@@ -1574,7 +1583,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma_bf16x6(wb[ot], bx, acc[ot][q]);
     }
-    if (!LL) trunk_group_wait(ctr, target, s_fail);
+    if (!LL) trunk_group_wait(ctr, target, s_fail, p.spin_limit);
     DLWP_STAMP();
     {   // weights of the wave's second mode: requested now, they arrive while the partials are awaited
       const int m = m_lo + wave + ROWS;
@@ -1604,7 +1613,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         if (LL) {
           int tries = 0;
           while (__any((va && (has_sentinel(v0) || has_sentinel(v2))) || (vb && (has_sentinel(v1) || has_sentinel(v3))))) {
-            if (++tries > (1 << 16)) {
+            if (++tries > p.try_limit) {
               *s_fail = 1;
               break;
             }
@@ -1674,7 +1683,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     }
     DLWP_STAMP();
     target += (unsigned)G;
-    if (!LL) trunk_group_barrier(ctr, target, s_fail);
+    if (!LL) trunk_group_barrier(ctr, target, s_fail, p.spin_limit);
     DLWP_STAMP();
     // ---- P3: inverse H-direction DFT for the own rows, columns (ky = wave, wave + ROWS, ..; o) -> s_z
     for (int ky = wave; ky < M2; ky += ROWS) {
@@ -1695,7 +1704,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
           int tries = 0;
           while (__any((k0 && has_sentinel(v0)) || (k1 && has_sentinel(v1)) || (k2 && has_sentinel(v2)) ||
                        (k3 && has_sentinel(v3)))) {
-            if (++tries > (1 << 16)) {
+            if (++tries > p.try_limit) {
               *s_fail = 1;
               break;
             }
@@ -1830,6 +1839,8 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   DLWP_STAMP();
 #undef DLWP_STAMP
   if (*s_fail) {
+    // loud failure: the host reads this word after the launch (DLWP_ERR_TIMEOUT / re-run on the unfused kernels)
+    if (tid == 0 && p.fail_word) __hip_atomic_store(p.fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float nanv = __uint_as_float(0x7fc00000u);
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -2063,10 +2074,8 @@ static int32_t launch_modes(const SpectralCore& sc, const float* ybuf, float* zb
   return fail(DLWP_ERR_UNSUPPORTED, "grid height %d > 256 not supported by the modes kernel", sc.H);
 }
 
-bool use_bf16x6_layer();
-
 template <bool SKIP, bool ACT, bool EMIT_Y>
-static int32_t launch_layer(const SpectralCore& sc, const LayerParams& lp, hipStream_t s) {
+static int32_t launch_layer(const SpectralCore& sc, const LayerParams& lp, hipStream_t s, bool bf16x6 = true) {
   // NO = 1 (row split between two waves, 4 waves/SIMD at the headline size) measured SLOWER than one
   // wave per row (16.6 vs 13.7 us event-timed: the duplicated x / Z / weight loads cost more than the
   // occupancy buys), so it stays off; kept as a template parameter for larger grids.
@@ -2084,7 +2093,7 @@ static int32_t launch_layer(const SpectralCore& sc, const LayerParams& lp, hipSt
     DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<16, SKIP, ACT, EMIT_Y, 1, SKIP>), lds));
     DLWP_HIP_CHECK(allow_lds((fno_layer_kernel<32, SKIP, ACT, EMIT_Y, 1, SKIP>), lds));
   }
-  const bool skipb = SKIP && lp.wsb != nullptr && use_bf16x6_layer();
+  const bool skipb = SKIP && lp.wsb != nullptr && bf16x6;
 #define DLWP_LAUNCH_LAYER(KP_, NO_)                                                                                \
   do {                                                                                                             \
     if (skipb)                                                                                                     \
@@ -2111,7 +2120,31 @@ using namespace dlwp::fno;
 // ---------------------------------------------------------------------------------------------
 // FNO2d plan
 // ---------------------------------------------------------------------------------------------
+// Every switch of the FNO path, fixed when the plan is created: the descriptor's fields, with the DLWP_* environment
+// variables only as debug defaults read at that moment.  Nothing process-global selects a kernel after that.
+struct FnoKnobs {
+  bool fp32_mfma = false;     // plain fp32-MFMA kernels + unfused spectral path (cross-check form)
+  bool trunk = true;          // fused trunk kernel (DLWP_FNO_TRUNK=0 disables)
+  int trunk_rows_forced = 0;  // DLWP_TRUNK_ROWS
+  bool step = true;           // whole step in one launch (DLWP_FNO_STEP=0 disables)
+  bool persistent = true;     // whole rollout range in one launch (DLWP_FNO_PERSISTENT=0 disables)
+  bool ll = true;             // flag-in-data hand-offs (DLWP_TRUNK_LL=0: counter barriers)
+  bool lift_only = false;     // diagnostics (DLWP_STEP_LIFT_ONLY)
+  int layer_stagger = 0;      // DLWP_LAYER_STAGGER
+  int spin_limit = 1 << 17, try_limit = 1 << 16;
+  int on_timeout = 0;         // 0: re-run the range on the unfused kernels, 1: return DLWP_ERR_TIMEOUT
+  int check = 1;              // 1: synchronise on the fail word after fused launches (default), 0: caller polls dlwp_fno2d_status
+  int cus = 0;                // compute units of the plan's device
+  int resident_per_cu = 0;    // fused-kernel workgroups the occupancy query admits per CU
+};
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 struct dlwp_fno2d_plan {
+  FnoKnobs k;
+  mutable std::atomic<unsigned> timeouts{0};   // statistics only: fused launches that timed out (re-run or reported)
   int cin = 0, hid_l = 0, hid_p = 0, cout = 0, L = 0, H = 0, W = 0;
   int cin_steps = 0;
   SpectralCore sc;
@@ -2178,6 +2211,8 @@ static void pack_w2(std::vector<float>& dst, const float* w2, int hid, int cout,
         }
 }
 
+namespace { int fused_resident_per_cu(int G); }
+
 extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2d_desc* d, void* stream) {
   DLWP_REQUIRE(out && d, DLWP_ERR_INVALID_ARGUMENT, "null plan/desc");
   *out = nullptr;
@@ -2197,7 +2232,32 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
   DLWP_REQUIRE(d->lift_w1 && d->lift_b1 && d->lift_w2 && d->lift_b2 && d->spec_w && d->spec_b && d->skip_w &&
                    d->proj_w1 && d->proj_b1 && d->proj_w2 && d->proj_b2 && d->rows_in && d->rows_out,
                DLWP_ERR_INVALID_ARGUMENT, "null weight pointer");
+  DLWP_REQUIRE(d->precision_form == 0 || d->precision_form == 1, DLWP_ERR_INVALID_ARGUMENT, "precision_form %d not in {0, 1}",
+               d->precision_form);
+  DLWP_REQUIRE(d->on_timeout == 0 || d->on_timeout == 1, DLWP_ERR_INVALID_ARGUMENT, "on_timeout %d not in {0, 1}", d->on_timeout);
+  DLWP_REQUIRE(d->debug_spin_limit >= 0, DLWP_ERR_INVALID_ARGUMENT, "debug_spin_limit must be >= 0");
   auto* p = new dlwp_fno2d_plan();
+  {
+    FnoKnobs& k = p->k;
+    // descriptor first; the environment only supplies debug defaults, read HERE and never again
+    k.fp32_mfma = d->precision_form == 1 || env_int("DLWP_FP32_MFMA", 0) != 0;
+    k.trunk = env_int("DLWP_FNO_TRUNK", 1) != 0 && d->launch_form != 3;
+    k.trunk_rows_forced = env_int("DLWP_TRUNK_ROWS", 0);
+    k.step = env_int("DLWP_FNO_STEP", 1) != 0 && d->launch_form != 2 && d->launch_form != 3;
+    k.persistent = env_int("DLWP_FNO_PERSISTENT", 1) != 0 && d->launch_form == 0;
+    k.ll = env_int("DLWP_TRUNK_LL", 1) != 0;
+    k.lift_only = env_int("DLWP_STEP_LIFT_ONLY", 0) != 0;
+    k.layer_stagger = env_int("DLWP_LAYER_STAGGER", 0);
+    if (d->debug_spin_limit > 0) k.spin_limit = k.try_limit = d->debug_spin_limit;
+    k.on_timeout = d->on_timeout;
+    k.check = d->unchecked ? 0 : 1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&k.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || k.cus <= 0) {
+      delete p;
+      return fail(DLWP_ERR_HIP, "cannot query the compute-unit count of the current device");
+    }
+  }
   p->cin = d->in_channels; p->hid_l = d->lifting_channels; p->hid_p = d->projection_channels;
   p->cout = d->out_channels; p->L = d->n_layers; p->H = d->height; p->W = d->width;
   p->cin_steps = (p->cin + 3) / 4;
@@ -2294,9 +2354,19 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
     delete p;
     return fail(DLWP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
   }
+  // Residency of the fused kernels (8-row workgroups, 512 threads, trunk_lds(8) bytes of LDS): the hand-offs spin on
+  // peer workgroups, so a launch may only hold as many workgroups as the occupancy query admits per CU x CUs.  A
+  // device that admits none (LDS or registers) gets the unfused kernels.
+  p->k.resident_per_cu = 0;
+  if (p->k.trunk && !p->k.fp32_mfma && p->H % 8 == 0) {
+    p->k.resident_per_cu = fused_resident_per_cu(p->H / 8);
+    if (p->k.resident_per_cu == 0) p->k.trunk = false;
+  }
   *out = p;
   return DLWP_OK;
 }
+
+extern "C" uint32_t dlwp_fno2d_timeouts(const dlwp_fno2d_plan* plan) { return plan ? plan->timeouts.load() : 0u; }
 
 extern "C" int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan) {
   delete plan;
@@ -2304,26 +2374,6 @@ extern "C" int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan) {
 }
 
 namespace {
-// delay of the second half of each layer-kernel workgroup (units of 2048 cycles); tunable for experiments
-int layer_stagger() {
-  static const int v = [] {
-    const char* e = getenv("DLWP_LAYER_STAGGER");
-    return e ? atoi(e) : 0;  // measured: every delay > 0 is slower (per-wave latency chain, not contention)
-  }();
-  return v;
-}
-
-// fp32 GEMMs on the bf16 matrix pipe (common.hpp "bf16x6"); DLWP_FP32_MFMA=1 selects the fp32-MFMA
-// kernels instead (kept for A/B measurements and as the numerical cross-check in the tests)
-int g_fp32_mfma = -1;  // -1: read DLWP_FP32_MFMA once, 0: bf16x6, 1: fp32 MFMA
-bool use_bf16x6() {
-  if (g_fp32_mfma < 0) {
-    const char* e = getenv("DLWP_FP32_MFMA");
-    g_fp32_mfma = (e && atoi(e) != 0) ? 1 : 0;
-  }
-  return g_fp32_mfma == 0;
-}
-
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
 struct KernelTimer {
   enum { LIFT = 0, MODES = 1, LAYER = 2, PROJ = 3, EMPTY = 4, NCLASS = 5 };
@@ -2347,9 +2397,11 @@ struct FnoWorkspace {
   float *xpart, *obuf;   // fused trunk: per-workgroup spectrum partials, mixed spectrum (two copies each)
   size_t xpart_half, obuf_half;   // floats per copy
   unsigned* ctr;         // fused trunk: one group counter per sample (128 B apart)
+  unsigned* fail;        // fused trunk: set by a workgroup whose hand-off spin ran out (zeroed by trunk_begin)
   size_t total;
 };
 constexpr size_t kCtrStrideBytes = 128;
+constexpr size_t kFailBytes = 256;
 FnoWorkspace carve(const dlwp_fno2d_plan* p, int B, void* base) {
   FnoWorkspace w;
   const size_t act = align_up((size_t)B * kC * p->H * p->W * 4, 256);
@@ -2367,9 +2419,10 @@ FnoWorkspace carve(const dlwp_fno2d_plan* p, int B, void* base) {
   w.xpart = reinterpret_cast<float*>(c + 2 * act + 2 * yz);
   w.obuf = reinterpret_cast<float*>(c + 2 * act + 2 * yz + xp);
   w.ctr = reinterpret_cast<unsigned*>(c + 2 * act + 2 * yz + xp + ob);
+  w.fail = reinterpret_cast<unsigned*>(c + 2 * act + 2 * yz + xp + ob + ct);
   w.xpart_half = xp / 8;
   w.obuf_half = ob / 8;
-  w.total = 2 * act + 2 * yz + xp + ob + ct;
+  w.total = 2 * act + 2 * yz + xp + ob + ct + kFailBytes;
   return w;
 }
 
@@ -2395,22 +2448,6 @@ int32_t launch_lift_cs(const MlpParams& mp, int kp, int grid, size_t lds, hipStr
 }
 
 // Fused trunk (fno_trunk_kernel): eligibility, counter reset, launch.
-int device_cu_count() {
-  static const int n = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return cus;
-  }();
-  return n;
-}
-bool trunk_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("DLWP_FNO_TRUNK");
-    return !(e && atoi(e) == 0);
-  }();
-  return on;
-}
 constexpr size_t trunk_lds(int rows) {
   return ((size_t)rows * kC * kTrStride + rows * kSyStride + rows * 16 * kC + rows * 128 + 2 * 16 * 64 + 4 + 2 * 2 * 16 * rows +
           6 * 3 * 64 * 4) *
@@ -2421,10 +2458,7 @@ constexpr size_t trunk_lds(int rows) {
 // SLOWER at the headline size (68 vs 51 us per launch: twice the partials to publish and sum, two ky columns per
 // wave in P1/P3); kept for grids whose height is not a multiple of 8 and selectable with DLWP_TRUNK_ROWS=4.
 int trunk_rows(const dlwp_fno2d_plan* p) {
-  static const int forced = [] {
-    const char* e = getenv("DLWP_TRUNK_ROWS");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = p->k.trunk_rows_forced;
   for (int rows : {8, 4}) {
     if (forced && rows != forced) continue;
     if (p->H % rows) continue;
@@ -2433,60 +2467,55 @@ int trunk_rows(const dlwp_fno2d_plan* p) {
     if (rows == 4 && G == 4) continue;
     if (rows == 8 && G == 32) continue;
     if ((p->sc.M1 * p->sc.M2 + G - 1) / G > 4 * rows) continue;    // at most 4 modes per wave in P2
-    if (G > device_cu_count() * (8 / rows)) continue;              // a sample's group must be resident at once
+    if (G > p->k.cus * (8 / rows)) continue;                       // a sample's group must be resident at once
     return rows;
   }
   return 0;
 }
 bool trunk_eligible(const dlwp_fno2d_plan* p) {
-  if (!trunk_enabled() || !use_bf16x6()) return false;
+  if (!p->k.trunk || p->k.fp32_mfma) return false;
   if (p->W != 64 || p->sc.KP != 16 || p->sc.M1 > 16 || p->L > kTrunkMaxLayers) return false;
   return trunk_rows(p) != 0;
 }
 // Whole step in one launch (STEP variant of the trunk kernel): needs the flag-in-data protocol, 8 rows per workgroup,
 // bf16x6 MLP weights that fit the transpose-tile LDS (widths <= 256, <= 16 input channels) and the FMA layer 2
 // of the projection (<= 4 outputs).  DLWP_FNO_STEP=0 keeps lifting / trunk / projection as three launches.
-bool step_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("DLWP_FNO_STEP");
-    return !(e && atoi(e) == 0);
-  }();
-  return on;
-}
 struct TrunkState {
   bool on = false;
   unsigned epoch = 0;    // group barriers already counted since the counters were zeroed
   unsigned layers = 0;   // spectral layers run since the exchange buffers were armed (flag-in-data protocol)
 };
-// Hand-off protocol of the fused trunk: 1 = flag-in-data (default), 0 = counter barriers (DLWP_TRUNK_LL=0).
-bool trunk_ll();
-// DLWP_FNO_PERSISTENT=0: one launch per step instead of one per rollout range
-bool rollout_persistent() {
-  static const bool on = [] {
-    const char* e = getenv("DLWP_FNO_PERSISTENT");
-    return !(e && atoi(e) == 0);
-  }();
-  return on;
-}
 bool step_eligible(const dlwp_fno2d_plan* p) {
-  return step_enabled() && trunk_eligible(p) && trunk_ll() && trunk_rows(p) == 8 && p->cin_steps <= 4 &&
+  return p->k.step && trunk_eligible(p) && p->k.ll && trunk_rows(p) == 8 && p->cin_steps <= 4 &&
          p->hid_l % 32 == 0 && p->hid_l <= 256 && p->hid_p <= 256 && p->proj_co > 0 && p->lift_w2b.p != nullptr &&
          p->proj_w1bp.p != nullptr;
 }
-bool trunk_ll() {
-  static const bool on = [] {
-    const char* e = getenv("DLWP_TRUNK_LL");
-    return !(e && atoi(e) == 0);
-  }();
-  return on;
+int fused_resident_per_cu(int G) {
+  int n = 0;
+  hipError_t oe = hipErrorInvalidValue;
+  constexpr size_t lds = trunk_lds(8);
+  auto query = [&](auto kern) {
+    oe = allow_lds(kern, lds);
+    if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 512, lds);
+  };
+  if (G == 4) query(fno_trunk_kernel<8, 4, true, true>);
+  else if (G == 8) query(fno_trunk_kernel<8, 8, true, true>);
+  else if (G == 16) query(fno_trunk_kernel<8, 16, true, true>);
+  else { oe = hipSuccess; n = 1; }
+  if (oe != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  // the fused kernels were tuned and verified at ONE workgroup per CU (the query says 1 at ~120 KB of LDS); never
+  // size a grid beyond that even if a later compiler build would admit two
+  return n >= 1 ? 1 : 0;
 }
-int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, TrunkState& st, hipStream_t s) {
-  st.on = trunk_eligible(p);
+int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, TrunkState& st, hipStream_t s,
+                    bool force_unfused = false) {
+  st.on = trunk_eligible(p) && !force_unfused;
   st.epoch = 0;
   st.layers = 0;
   if (st.on) {
-    DLWP_HIP_CHECK(hipMemsetAsync(ws.ctr, 0, 2 * align_up((size_t)B * kCtrStrideBytes, 256), s));
-    if (trunk_ll()) {   // arm both copies of both exchange buffers with the sentinel
+    // group counters, XCC-id table and the fail word behind them
+    DLWP_HIP_CHECK(hipMemsetAsync(ws.ctr, 0, 2 * align_up((size_t)B * kCtrStrideBytes, 256) + kFailBytes, s));
+    if (p->k.ll) {   // arm both copies of both exchange buffers with the sentinel
       DLWP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.xpart), (int)kSentinel, 2 * ws.xpart_half, s));
       DLWP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.obuf), (int)kSentinel, 2 * ws.obuf_half, s));
     }
@@ -2502,9 +2531,9 @@ hipError_t step_launch_one(const TrunkParams& tp, hipStream_t s) {
   return hipGetLastError();
 }
 template <int ROWS, int G>
-hipError_t trunk_launch_one(const TrunkParams& tp, hipStream_t s) {
+hipError_t trunk_launch_one(const TrunkParams& tp, hipStream_t s, bool ll) {
   constexpr size_t lds = trunk_lds(ROWS);
-  if (trunk_ll()) {
+  if (ll) {
     hipError_t e = allow_lds(fno_trunk_kernel<ROWS, G, true>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((fno_trunk_kernel<ROWS, G, true>), dim3(tp.S * G), dim3(64 * ROWS), lds, s, tp);
@@ -2534,7 +2563,9 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
   const int rows = trunk_rows(p);
   DLWP_REQUIRE(rows > 0, DLWP_ERR_UNSUPPORTED, "fused trunk not available for this plan");
   const int G = p->H / rows;
-  int per_launch = device_cu_count() * (8 / rows) / G;
+  // residency: every workgroup of a launch must be on the chip at once (the hand-offs spin on peers).  The grid is
+  // bounded by what the occupancy query admitted for the fused kernel at plan creation x the CU count.
+  int per_launch = p->k.cus * (rows == 8 ? p->k.resident_per_cu : 8 / rows) / G;
   if (per_launch >= 8) per_launch &= ~7;   // keeps the same-XCD group mapping
   DLWP_REQUIRE(per_launch > 0, DLWP_ERR_UNSUPPORTED, "a sample needs %d workgroups, more than fit the device", G);
   const size_t nm = (size_t)p->sc.M1 * p->sc.M2 * 64;
@@ -2556,6 +2587,7 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
     tp.xpart_par = (long long)ws.xpart_half; tp.obuf_par = (long long)ws.obuf_half; tp.layer0 = st.layers;
     tp.xcc_tab = ws.ctr + align_up((size_t)B * kCtrStrideBytes, 256) / 4 + (size_t)s0 * 32;
     tp.H = p->H; tp.L = p->L; tp.M1 = p->sc.M1; tp.M2 = p->sc.M2; tp.G = G; tp.sample0 = s0;
+    tp.spin_limit = p->k.spin_limit; tp.try_limit = p->k.try_limit; tp.fail_word = ws.fail;
     // diagnostics: DLWP_TRUNK_TRACE=<file> dumps per-workgroup phase timestamps of the first few launches
     static const char* trace_path = getenv("DLWP_TRUNK_TRACE");
     static unsigned long long* trace_buf = nullptr;
@@ -2587,12 +2619,12 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
       else if (G == 8) le = step_launch_one<8>(tp, s);
       else if (G == 16) le = step_launch_one<16>(tp, s);
     } else
-    if (rows == 8 && G == 4) le = trunk_launch_one<8, 4>(tp, s);
-    else if (rows == 8 && G == 8) le = trunk_launch_one<8, 8>(tp, s);
-    else if (rows == 8 && G == 16) le = trunk_launch_one<8, 16>(tp, s);
-    else if (rows == 4 && G == 8) le = trunk_launch_one<4, 8>(tp, s);
-    else if (rows == 4 && G == 16) le = trunk_launch_one<4, 16>(tp, s);
-    else if (rows == 4 && G == 32) le = trunk_launch_one<4, 32>(tp, s);
+    if (rows == 8 && G == 4) le = trunk_launch_one<8, 4>(tp, s, p->k.ll);
+    else if (rows == 8 && G == 8) le = trunk_launch_one<8, 8>(tp, s, p->k.ll);
+    else if (rows == 8 && G == 16) le = trunk_launch_one<8, 16>(tp, s, p->k.ll);
+    else if (rows == 4 && G == 8) le = trunk_launch_one<4, 8>(tp, s, p->k.ll);
+    else if (rows == 4 && G == 16) le = trunk_launch_one<4, 16>(tp, s, p->k.ll);
+    else if (rows == 4 && G == 32) le = trunk_launch_one<4, 32>(tp, s, p->k.ll);
     DLWP_HIP_CHECK(le);
     if (tp.trace) {
       std::vector<unsigned long long> hbuf((size_t)tp.S * G * 64);
@@ -2636,7 +2668,7 @@ int32_t fno_project(const dlwp_fno2d_plan* p, const float* hin, int B, float* ou
     if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::PROJ));
     if (p->proj_co > 0) {
       mp.w2p = p->proj_w2v.as<float>();
-      const bool bf = use_bf16x6();
+      const bool bf = !p->k.fp32_mfma;
       if (bf) mp.w1p = p->proj_w1b.as<float>();
       const size_t lds2 = bf ? ((size_t)nt * 3 * 64 * 4 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4
                              : ((size_t)nt * 8 * 64 + p->hid_p + (size_t)nt * p->proj_co * 16) * 4;
@@ -2667,6 +2699,23 @@ int32_t fno_project(const dlwp_fno2d_plan* p, const float* hin, int B, float* ou
   return DLWP_OK;
 }
 
+// Reads the fail word of the fused launches enqueued so far on `s` (synchronises the stream).  Returns 1 if a hand-off
+// timed out, 0 if not, < 0 on a HIP error.  Skipped (returns 0) while the stream is being captured into a graph.
+int read_fail_word(const FnoWorkspace& ws, hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
+  thread_local unsigned* h_word = nullptr;   // pinned, one per host thread (like dlwp_last_error); never freed
+  if (!h_word && hipHostMalloc(reinterpret_cast<void**>(&h_word), 64, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    h_word = nullptr;
+    return -1;
+  }
+  *h_word = 0u;
+  if (hipMemcpyAsync(h_word, ws.fail, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  return *h_word ? 1 : 0;
+}
+
 // one backbone step: x (channel table) -> out (+ resid)
 int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const FnoWorkspace& ws, float* out,
                  long long out_bstride, const float* resid, long long resid_bstride, hipStream_t s,
@@ -2681,7 +2730,7 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     StepIO io;
     io.in = &xt; io.out = out; io.out_bstride = out_bstride; io.resid = resid; io.resid_bstride = resid_bstride;
     if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::LAYER));
-    static const bool lift_only = [] { const char* e = getenv("DLWP_STEP_LIFT_ONLY"); return e && atoi(e) != 0; }();
+    const bool lift_only = p->k.lift_only;
     io.lift_only = lift_only;
     const int32_t rc = launch_trunk(p, ws, B, nullptr, lift_only ? ws.h1 : nullptr, *trunk, s, &io);
     if (rc != DLWP_OK) return rc;
@@ -2701,7 +2750,7 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     mp.B = B; mp.H = p->H; mp.W = p->W;
     const int nt = p->hid_l / 16;
     const size_t lds = ((size_t)nt * p->cin_steps * 64 + p->hid_l + (size_t)nt * 4 * 2 * 64 + 4 * kC * kTrStride) * 4;
-    const bool bf = use_bf16x6() && p->lift_w2b.p != nullptr;
+    const bool bf = !p->k.fp32_mfma && p->lift_w2b.p != nullptr;
     // 8-wave workgroups: the ~53 KB of staged weights are shared by 8 rows and one workgroup per CU
     // keeps 2 waves per SIMD resident (4-wave workgroups at 88 KB of LDS ran one per CU, in two rounds)
     const size_t lds_bf = ((size_t)(nt / 2) * 6 * 64 * 4 + (size_t)nt * p->cin_steps * 64 + p->hid_l + 8 * kC * kTrStride) * 4;
@@ -2741,11 +2790,12 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
     lp.x = hin; lp.y = hout; lp.wsp = p->wsp[l].as<float>(); lp.wsb = p->wsb[l].as<u32x4>(); lp.bias = p->sbias[l].as<float>();
     lp.zbuf = ws.zbuf; lp.t = p->sc.t.as<float>(); lp.tt = p->sc.tt.as<float>(); lp.ybuf = ws.ybuf;
     lp.B = B; lp.H = p->H; lp.W = p->W;
-    lp.stagger = layer_stagger();
+    lp.stagger = p->k.layer_stagger;
     const bool last = (l == p->L - 1);
     // neuralop FNOBlocks.forward_with_postactivation: GELU after every layer but the last
     if (timer) DLWP_HIP_CHECK(timer->begin(KernelTimer::LAYER));
-    rc = last ? launch_layer<true, false, false>(p->sc, lp, s) : launch_layer<true, true, true>(p->sc, lp, s);
+    rc = last ? launch_layer<true, false, false>(p->sc, lp, s, !p->k.fp32_mfma)
+              : launch_layer<true, true, true>(p->sc, lp, s, !p->k.fp32_mfma);
     if (rc != DLWP_OK) return rc;
     if (timer) DLWP_HIP_CHECK(timer->end(KernelTimer::LAYER));
     float* t = hin; hin = hout; hout = t;
@@ -2753,14 +2803,6 @@ int32_t fno_step(const dlwp_fno2d_plan* p, const ChanTable& xt, int B, const Fno
   return fno_project(p, hin, B, out, out_bstride, resid, resid_bstride, s, timer);
 }
 }  // namespace
-
-namespace dlwp { namespace fno { bool use_bf16x6_layer() { return use_bf16x6(); } } }
-
-extern "C" int32_t dlwp_set_fp32_mfma(int32_t on) {
-  const int32_t prev = use_bf16x6() ? 0 : 1;
-  g_fp32_mfma = on ? 1 : 0;
-  return prev;
-}
 
 extern "C" size_t dlwp_fno2d_workspace_bytes(const dlwp_fno2d_plan* plan, int32_t batch) {
   if (!plan || batch <= 0) return 0;
@@ -2780,17 +2822,73 @@ extern "C" int32_t dlwp_fno2d_forward_f32(const dlwp_fno2d_plan* plan, const flo
   ChanTable xt;
   xt.seg[0] = ChanSeg{x, plan->cin * HW, plan->cin, 0};
   for (int i = 1; i < 4; ++i) xt.seg[i] = ChanSeg{nullptr, 0, 0, 0};
-  TrunkState trunk;
-  const int32_t rc0 = trunk_begin(plan, ws, batch, trunk, reinterpret_cast<hipStream_t>(stream));
-  if (rc0 != DLWP_OK) return rc0;
-  return fno_step(plan, xt, batch, ws, y, plan->cout * HW, nullptr, 0, reinterpret_cast<hipStream_t>(stream), &trunk);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    TrunkState trunk;
+    const int32_t rc0 = trunk_begin(plan, ws, batch, trunk, s, /*force_unfused=*/attempt == 1);
+    if (rc0 != DLWP_OK) return rc0;
+    const int32_t rc = fno_step(plan, xt, batch, ws, y, plan->cout * HW, nullptr, 0, s, &trunk);
+    if (rc != DLWP_OK || !trunk.on || !plan->k.check) return rc;
+    const int f = read_fail_word(ws, s);
+    if (f < 0) return fail(DLWP_ERR_HIP, "reading the fused kernel's fail word failed");
+    if (f == 0) return DLWP_OK;
+    plan->timeouts.fetch_add(1);
+    if (plan->k.on_timeout == 1)
+      return fail(DLWP_ERR_TIMEOUT, "fused FNO step: a workgroup hand-off exceeded its spin bound (output poisoned with NaN)");
+  }
+  return fail(DLWP_ERR_TIMEOUT, "unreachable: the unfused kernels have no hand-offs");
 }
 
+extern "C" int32_t dlwp_fno2d_status(const dlwp_fno2d_plan* plan, int32_t batch, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  DLWP_REQUIRE(plan && workspace && batch > 0, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  const FnoWorkspace ws = carve(plan, batch, workspace);
+  DLWP_REQUIRE(workspace_bytes >= ws.total, DLWP_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
+  const int f = read_fail_word(ws, reinterpret_cast<hipStream_t>(stream));
+  if (f < 0) return fail(DLWP_ERR_HIP, "reading the fused kernel's fail word failed");
+  if (f == 1) {
+    plan->timeouts.fetch_add(1);
+    return fail(DLWP_ERR_TIMEOUT, "fused FNO launch: a workgroup hand-off exceeded its spin bound (output poisoned with NaN)");
+  }
+  return DLWP_OK;
+}
+
+static int32_t fno_rollout_once(const dlwp_fno2d_plan* plan, const float* constants, int32_t n_const,
+                                const float* prescribed, int32_t n_presc, const float* prognostic,
+                                int32_t n_prog, int32_t batch, int32_t n_time, int32_t context, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream, KernelTimer* timer,
+                                int32_t step_begin, int32_t step_end, bool force_unfused, bool* used_fused);
+
+// Checked rollout: run the range; if fused kernels were used, read their fail word (one stream synchronisation per
+// call); on a timeout either report DLWP_ERR_TIMEOUT (on_timeout = 1) or re-run the SAME range on the unfused
+// kernels, which have no inter-workgroup hand-offs and cannot time out (the inputs are untouched: the range only
+// writes out[:, step_begin:step_end]).
 static int32_t fno_rollout_impl(const dlwp_fno2d_plan* plan, const float* constants, int32_t n_const,
                                 const float* prescribed, int32_t n_presc, const float* prognostic,
                                 int32_t n_prog, int32_t batch, int32_t n_time, int32_t context, float* out,
                                 void* workspace, size_t workspace_bytes, void* stream, KernelTimer* timer,
                                 int32_t step_begin = 0, int32_t step_end = -1) {
+  bool fused = false;
+  int32_t rc = fno_rollout_once(plan, constants, n_const, prescribed, n_presc, prognostic, n_prog, batch, n_time, context,
+                                out, workspace, workspace_bytes, stream, timer, step_begin, step_end, false, &fused);
+  if (rc != DLWP_OK || !fused || !plan->k.check) return rc;
+  const FnoWorkspace ws = carve(plan, batch, workspace);
+  const int f = read_fail_word(ws, reinterpret_cast<hipStream_t>(stream));
+  if (f < 0) return fail(DLWP_ERR_HIP, "reading the fused kernel's fail word failed");
+  if (f == 0) return DLWP_OK;
+  plan->timeouts.fetch_add(1);
+  if (plan->k.on_timeout == 1)
+    return fail(DLWP_ERR_TIMEOUT, "fused FNO rollout: a workgroup hand-off exceeded its spin bound (steps [%d, %d) poisoned "
+                "with NaN); were all %d workgroups of the launch resident?", step_begin, step_end, batch * (plan->H / 8));
+  return fno_rollout_once(plan, constants, n_const, prescribed, n_presc, prognostic, n_prog, batch, n_time, context, out,
+                          workspace, workspace_bytes, stream, nullptr, step_begin, step_end, true, &fused);
+}
+
+static int32_t fno_rollout_once(const dlwp_fno2d_plan* plan, const float* constants, int32_t n_const,
+                                const float* prescribed, int32_t n_presc, const float* prognostic,
+                                int32_t n_prog, int32_t batch, int32_t n_time, int32_t context, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream, KernelTimer* timer,
+                                int32_t step_begin, int32_t step_end, bool force_unfused, bool* used_fused) {
   DLWP_REQUIRE(plan && prognostic && out && workspace, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0 && context >= 1 && n_time > context, DLWP_ERR_INVALID_ARGUMENT,
                "need batch > 0, context >= 1, n_time > context (got %d, %d, %d)", batch, context, n_time);
@@ -2815,10 +2913,11 @@ static int32_t fno_rollout_impl(const dlwp_fno2d_plan* plan, const float* consta
                "step range [%d, %d) outside [0, %d]", step_begin, step_end, To);
   TrunkState trunk;
   {
-    const int32_t rc0 = trunk_begin(plan, ws, batch, trunk, s);
+    const int32_t rc0 = trunk_begin(plan, ws, batch, trunk, s, force_unfused);
     if (rc0 != DLWP_OK) return rc0;
   }
-  if (trunk.on && step_eligible(plan) && rollout_persistent() && step_end - step_begin > 1) {
+  *used_fused = trunk.on;
+  if (trunk.on && step_eligible(plan) && plan->k.persistent && step_end - step_begin > 1) {
     // the whole range in ONE launch: no host in the loop, no launch gaps (reported in the LAYER class)
     ChanTable none;
     for (int i = 0; i < 4; ++i) none.seg[i] = ChanSeg{nullptr, 0, 0, 0};

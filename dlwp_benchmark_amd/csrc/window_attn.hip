@@ -493,22 +493,6 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
 }  // namespace wattn
 }  // namespace dlwp
 
-// which fp32-accurate form dlwp_window_attn_f32 runs: 0 fp32 MFMA, 1 bf16x6, -1 by window size (default)
-static int g_wattn_bf16x6 = -2;   // -2: read DLWP_WATTN_BF16X6 once
-static int wattn_bf16x6_mode() {
-  if (g_wattn_bf16x6 == -2) {
-    const char* e = getenv("DLWP_WATTN_BF16X6");
-    g_wattn_bf16x6 = e ? (atoi(e) > 0 ? 1 : (atoi(e) < 0 ? -1 : 0)) : -1;
-  }
-  return g_wattn_bf16x6;
-}
-
-extern "C" int32_t dlwp_set_window_attn_bf16x6(int32_t mode) {
-  const int32_t prev = wattn_bf16x6_mode();
-  g_wattn_bf16x6 = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
-  return prev;
-}
-
 using namespace dlwp;
 using namespace dlwp::wattn;
 
@@ -614,13 +598,12 @@ static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, cons
 
 extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
                                         const float* table, float* out, int32_t batch, void* stream) {
-  // fp32-accurate either way.  By default (mode -1) by window size, as measured: whole-map windows (Swin C3, 2048
-  // tokens) take the same time per call in both forms -- the kernel is bound by its VALU work and the splits add what
-  // the cheaper MFMAs give back -- and keep the fp32-MFMA kernel; small windows (Pangu C5, 144 tokens, head_dim 32)
-  // are 4 % faster per model step with bf16x6.  dlwp_set_window_attn_bf16x6(0 / 1) forces one form (cross-check).
-  const int mode = wattn_bf16x6_mode();
-  const int n_win = u ? u->window[0] * u->window[1] * u->window[2] : 0;
-  const bool x6 = mode > 0 || (mode < 0 && n_win < 512);
+  // fp32-accurate either way; desc->form picks the form of the two contractions: 0 fp32 MFMA, 1 bf16x6, -1 by window
+  // size as measured (whole-map windows, >= 512 tokens: fp32 MFMA; small windows: bf16x6).  Each is the other's cross-check.
+  DLWP_REQUIRE(u, DLWP_ERR_INVALID_ARGUMENT, "null descriptor");
+  DLWP_REQUIRE(u->form >= -1 && u->form <= 1, DLWP_ERR_INVALID_ARGUMENT, "form %d not in {-1, 0, 1}", u->form);
+  const int n_win = u->window[0] * u->window[1] * u->window[2];
+  const bool x6 = u->form > 0 || (u->form < 0 && n_win < 512);
   return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, x6 ? 2 : 0);
 }
 

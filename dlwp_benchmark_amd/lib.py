@@ -26,6 +26,8 @@ class FNO2dDesc(ctypes.Structure):
         ("lift_w1", c_void_p), ("lift_b1", c_void_p), ("lift_w2", c_void_p), ("lift_b2", c_void_p),
         ("spec_w", POINTER(c_void_p)), ("spec_b", c_void_p), ("skip_w", POINTER(c_void_p)),
         ("proj_w1", c_void_p), ("proj_b1", c_void_p), ("proj_w2", c_void_p), ("proj_b2", c_void_p),
+        ("precision_form", c_int32), ("launch_form", c_int32), ("on_timeout", c_int32), ("unchecked", c_int32),
+        ("debug_spin_limit", c_int32),
     ]
 
 
@@ -35,7 +37,7 @@ class WAttnDesc(ctypes.Structure):
         ("grid", c_int32 * 3), ("padded", c_int32 * 3), ("pad_lead", c_int32 * 3), ("window", c_int32 * 3),
         ("shift_fwd", c_int32 * 3), ("shift_back", c_int32 * 3), ("use_mask", c_int32),
         ("mask_b1", c_int32 * 3), ("mask_b2", c_int32 * 3), ("bias_mode", c_int32),
-        ("heads", c_int32), ("head_dim", c_int32), ("scale", c_float),
+        ("heads", c_int32), ("head_dim", c_int32), ("scale", c_float), ("form", c_int32),
     ]
 
 
@@ -44,11 +46,11 @@ SIGNATURES = {
     "dlwp_version": (c_int32, []),
     "dlwp_last_error": (c_char_p, []),
     "dlwp_device_count": (c_int32, []),
-    "dlwp_set_fp32_mfma": (c_int32, [c_int32]),
-    "dlwp_set_window_attn_bf16x6": (c_int32, [c_int32]),
     "dlwp_fno2d_plan_create": (c_int32, [POINTER(c_void_p), POINTER(FNO2dDesc), c_void_p]),
     "dlwp_fno2d_plan_destroy": (c_int32, [c_void_p]),
     "dlwp_fno2d_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "dlwp_fno2d_status": (c_int32, [c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "dlwp_fno2d_timeouts": (ctypes.c_uint32, [c_void_p]),
     "dlwp_fno2d_forward_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "dlwp_fno2d_rollout_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                                          c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -6,12 +6,12 @@ drop-in is a package that exports the same CLASS NAMES (live names of :6-12 plus
 FNO2DModule / ConvLSTM of :4-5 that the north star covers).  Put this package in front of `sys.path`
 as `models` or import from here directly.
 """
-from .fno import FNO2DModule
+from .fno import FNO2DModule, TFNO2DModule
 from .fourcastnet import AFNONet, FourCastNet
 from .pangu import PanguWeather
 from .spectral import SpectralConv2d
 from .swin import SwinTransformer, SwinTransformerHPX
-from .unet import ConvLSTM, HEALPixLayer, HEALPixPadding, MUNetHPX, UNet, UNetHPX
+from .unet import ConvLSTM, ConvLSTMHPX, HEALPixLayer, HEALPixPadding, ModernUNet, MUNetHPX, UNet, UNetHPX
 
-__all__ = ["FNO2DModule", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "SwinTransformerHPX", "UNet",
+__all__ = ["FNO2DModule", "TFNO2DModule", "ConvLSTMHPX", "ModernUNet", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "SwinTransformerHPX", "UNet",
            "UNetHPX", "MUNetHPX", "ConvLSTM", "HEALPixPadding", "HEALPixLayer"]

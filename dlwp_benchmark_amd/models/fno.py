@@ -139,6 +139,10 @@ def kept_rows(h: int, n_modes_h: int):
 
 
 class FNO2DModule(HipBackbone):
+    # the rollout is ONE persistent launch that needs every compute unit resident at once: nothing else (an RCCL
+    # kernel of an overlapped collective) may occupy the chip beside it -- sharding.ShardedRollout honours this
+    exclusive_launch = True
+
     def __init__(self, n_modes: list = [12, 12], constant_channels: int = 4, prescribed_channels: int = 1,
                  prognostic_channels: int = 8, hidden_channels: int = 32, lifting_channels: int = 256,
                  projection_channels: int = 256, n_layers: int = 4, max_n_modes: int = None, bias: bool = True,
@@ -164,6 +168,31 @@ class FNO2DModule(HipBackbone):
                         out_channels=prognostic_channels, n_layers=n_layers, tucker_rank_=_tucker_rank)
         self._plan = None
         self._plan_key = None
+        # execution form of the plan (struct dlwp_fno2d_desc): per-module state, fixed per plan, no process-wide switch
+        self.precision_form = "bf16x6"   # or "fp32_mfma": plain fp32-MFMA kernels + unfused spectral path (cross-check)
+        self.launch_form = 0             # 0 fewest launches, 1 one per step, 2 three per step, 3 unfused kernels
+        self.on_timeout = "rerun"        # or "raise": DLWP_ERR_TIMEOUT instead of the automatic re-run on the unfused kernels
+        self._debug_spin_limit = 0       # test hook: tiny hand-off spin bound to force the timeout path
+
+    def set_execution_form(self, precision_form: Optional[str] = None, launch_form: Optional[int] = None,
+                           on_timeout: Optional[str] = None):
+        if precision_form is not None:
+            if precision_form not in ("bf16x6", "fp32_mfma"):
+                raise _lib.DlwpError(f"unknown precision_form {precision_form!r}")
+            self.precision_form = precision_form
+        if launch_form is not None:
+            if launch_form not in (0, 1, 2, 3):
+                raise _lib.DlwpError(f"unknown launch_form {launch_form!r}")
+            self.launch_form = int(launch_form)
+        if on_timeout is not None:
+            if on_timeout not in ("rerun", "raise"):
+                raise _lib.DlwpError(f"unknown on_timeout {on_timeout!r}")
+            self.on_timeout = on_timeout
+        return self
+
+    def fused_timeouts(self) -> int:
+        """fused launches of the current plan whose hand-off spin ran out (re-run on the unfused kernels or raised)"""
+        return int(_lib.load().dlwp_fno2d_timeouts(self._plan)) if self._plan is not None else 0
 
     # ------------------------------------------------------------------ plan management
     def _destroy_plan(self):
@@ -181,7 +210,8 @@ class FNO2DModule(HipBackbone):
             pass
 
     def _get_plan(self, h: int, w: int, device):
-        key = (h, w, str(device), self._param_key())
+        key = (h, w, str(device), self._param_key(), self.precision_form, self.launch_form, self.on_timeout,
+               self._debug_spin_limit)
         if self._plan is not None and key == self._plan_key:
             return self._plan
         self._destroy_plan()
@@ -231,6 +261,11 @@ class FNO2DModule(HipBackbone):
         d.proj_b1 = ptr(host(f.projection.fcs[0].bias))
         d.proj_w2 = ptr(host(f.projection.fcs[1].weight).reshape(d.out_channels, -1).contiguous())
         d.proj_b2 = ptr(host(f.projection.fcs[1].bias))
+        d.precision_form = 1 if self.precision_form == "fp32_mfma" else 0
+        d.launch_form = int(self.launch_form)
+        d.on_timeout = 1 if self.on_timeout == "raise" else 0
+        d.unchecked = 0
+        d.debug_spin_limit = int(self._debug_spin_limit)
         plan = ctypes.c_void_p()
         with torch.cuda.device(device):
             _lib.check(lib.dlwp_fno2d_plan_create(ctypes.byref(plan), ctypes.byref(d), _lib.stream_ptr()),

@@ -200,7 +200,10 @@ class SwinTransformer(HipBackbone):
         return self
 
     def set_attention_precision(self, precision: str):
-        """"fp32" (default, parity path) or "bf16" (bf16 MFMA operands, fp32 accumulate / softmax)."""
+        """"fp32" (default, parity path; "fp32_mfma" / "bf16x6" force one of its two fp32-accurate forms) or "bf16"
+        (bf16 MFMA operands, fp32 accumulate / softmax).  Per-module state, no process-wide switch."""
+        if precision not in ("fp32", "fp32_mfma", "bf16x6", "bf16"):
+            raise _lib.DlwpError(f"unknown attention precision {precision!r}")
         for m in self.modules():
             if hasattr(m, "attention_precision"):
                 m.attention_precision = precision

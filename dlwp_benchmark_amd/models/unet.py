@@ -84,8 +84,6 @@ class ResidualBlock(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, activation=None, norm: bool = False, n_groups: int = 1,
                  kernel_size=3, padding=1, mesh=None):
         super().__init__()
-        if mesh != "healpix":
-            raise NotImplementedError("ModernUNet is only runnable on the HEALPix mesh in the reference (SURVEY.md 8c)")
         if kernel_size != 3:
             raise NotImplementedError("only 3x3 residual blocks have a fused kernel")
         activation = _resolve_activation(activation) if activation is not None else nn.GELU()
@@ -93,7 +91,10 @@ class ResidualBlock(nn.Module):
             raise NotImplementedError("ResidualBlock: only GELU (the reference default) is wired to the fused kernels")
         self.activation = activation
         self.mesh = mesh
-        self.cylinder_pad = HEALPixPadding(padding=1)
+        # unet.py:867-872: HEALPixPadding on the HEALPix mesh, CylinderPad otherwise; either way the padding happens
+        # inside the fused convolution kernel
+        self.cylinder_pad = HEALPixPadding(padding=1) if mesh == "healpix" else CylinderPad(1)
+        self._conv = ops.conv3x3_hpx if mesh == "healpix" else ops.conv3x3_cyl
         self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=0)
         self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=0)
         with torch.no_grad():   # zero_module (unet.py:762-766)
@@ -107,10 +108,10 @@ class ResidualBlock(nn.Module):
         gelu = ops.act_code(self.activation)
         h = F.gelu(self.norm1(x))
         if isinstance(self.norm2, nn.Identity):
-            h = ops.conv3x3_hpx(h, self.conv1.weight, self.conv1.bias, gelu)
+            h = self._conv(h, self.conv1.weight, self.conv1.bias, gelu)
         else:
-            h = F.gelu(self.norm2(ops.conv3x3_hpx(h, self.conv1.weight, self.conv1.bias, 0)))
-        h = ops.conv3x3_hpx(h, self.conv2.weight, self.conv2.bias, 0)
+            h = F.gelu(self.norm2(self._conv(h, self.conv1.weight, self.conv1.bias, 0)))
+        h = self._conv(h, self.conv2.weight, self.conv2.bias, 0)
         return h + self.shortcut(x)
 
 
@@ -309,10 +310,18 @@ class UNetHPX(UNet):
             return out.reshape(b, f, t_total - ctx, cg, h, w).permute(0, 2, 3, 1, 4, 5).contiguous()
 
 
-class _ModernUNetEncoder(nn.Module):
-    """unet.py:559-632, healpix branch."""
+def _res_layer(c_in, c_out, mesh):
+    """unet.py:588-610 / :663-683: the residual block of an encoder / decoder level, wrapped in a HEALPixLayer on the
+    HEALPix mesh (state-dict key `...layers.0.conv1`), bare otherwise (`...conv1`)."""
+    if mesh == "healpix":
+        return HEALPixLayer(layer=ResidualBlock, in_channels=c_in, out_channels=c_out, kernel_size=3, padding=0, mesh="healpix")
+    return ResidualBlock(in_channels=c_in, out_channels=c_out, kernel_size=3, padding=1)
 
-    def __init__(self, in_channels, hidden_channels):
+
+class _ModernUNetEncoder(nn.Module):
+    """unet.py:559-632."""
+
+    def __init__(self, in_channels, hidden_channels, mesh="healpix"):
         super().__init__()
         self.attn = nn.Identity()
         channels = [in_channels] + list(hidden_channels)
@@ -320,8 +329,7 @@ class _ModernUNetEncoder(nn.Module):
         for c_idx in range(len(channels) - 1):
             c_in, c_out = channels[c_idx], channels[c_idx + 1]
             first = nn.Conv2d(c_in, c_in, (3, 3), (2, 2), (1, 1)) if c_idx > 0 else nn.Conv2d(c_in, c_in, (1, 1), (1, 1), (0, 0))
-            layers.append(nn.Sequential(first, HEALPixLayer(layer=ResidualBlock, in_channels=c_in, out_channels=c_out,
-                                                             kernel_size=3, padding=0, mesh="healpix"), self.attn))
+            layers.append(nn.Sequential(first, _res_layer(c_in, c_out, mesh), self.attn))
         self.layers = nn.ModuleList(layers)
 
     def forward(self, x):
@@ -335,7 +343,7 @@ class _ModernUNetDecoder(nn.Module):
     instances, the sub-modules are HEALPixLayer wrappers, so no skip is ever concatenated (the channel counts of
     the constructor are consistent with exactly that)."""
 
-    def __init__(self, hidden_channels, out_channels, activation):
+    def __init__(self, hidden_channels, out_channels, activation, mesh="healpix"):
         super().__init__()
         final_out = 2 * hidden_channels[0]
         hidden = list(hidden_channels)[::-1]
@@ -347,10 +355,7 @@ class _ModernUNetDecoder(nn.Module):
             c_out = hidden[c_idx]
             c_in_ = c_out if c_idx == 0 else 2 * hidden[c_idx]
             c_out2 = 2 * hidden[c_idx + 1] if c_idx + 1 < len(hidden) else 2 * hidden[c_idx]
-            layer = [HEALPixLayer(layer=ResidualBlock, in_channels=c_in_, out_channels=c_out, kernel_size=3, padding=0,
-                                  mesh="healpix"), self.attn,
-                     HEALPixLayer(layer=ResidualBlock, in_channels=c_out, out_channels=c_out2, kernel_size=3, padding=0,
-                                  mesh="healpix")]
+            layer = [_res_layer(c_in_, c_out, mesh), self.attn, _res_layer(c_out, c_out2, mesh)]
             if c_idx < len(hidden) - 1:
                 layer.append(nn.ConvTranspose2d(c_out2, c_out2, (4, 4), (2, 2), (1, 1)))
             layers.append(nn.Sequential(*layer))
@@ -393,67 +398,167 @@ class MUNetHPX(UNetHPX):
         return self.decoder(self.middle(self.encoder(x)))
 
 
+class ModernUNet(UNet):
+    """Registry name `ModernUNet` (reference models/unet/unet.py:72-203; the `type` of seven configs/model/modernunet*.yaml).
+    The reference class CANNOT be constructed with mesh="equirectangular" -- the only mesh those configs give it --
+    because its decoder defines `c_out2` inside the healpix branch only (unet.py:705-719: NameError), and with the
+    skip concatenation of :747-751 active its channel counts would not line up either.  There is therefore NO
+    reference behaviour to be faithful to on the lat-lon grid (PARITY UNPINNED by necessity).
+    What this class does: mesh="healpix" is MUNetHPX (pinned by fixtures of the real class); mesh="equirectangular"
+    builds the same network as it RUNS on the HEALPix mesh (no skip concatenation, :747-751) with the lat-lon
+    residual block of :867-872 (CylinderPad instead of HEALPixPadding; strided / transposed convolutions zero-padded
+    as constructed at :583, :719), so the reference's model configs construct and roll out through the HIP kernels."""
+
+    def __new__(cls, *args, **kwargs):
+        if cls is ModernUNet and kwargs.get("mesh", "equirectangular") == "healpix":
+            return MUNetHPX(*args, **kwargs)
+        return super().__new__(cls)
+
+    def __init__(self, constant_channels: int = 4, prescribed_channels: int = 0, prognostic_channels: int = 1,
+                 hidden_channels: list = [64, 128, 256, 1024], activation=nn.GELU(), context_size: int = 1,
+                 mesh: str = "equirectangular", attention: bool = False, norm: bool = False, recurrent: bool = False,
+                 **kwargs):
+        HipBackbone.__init__(self)
+        if mesh != "equirectangular":
+            raise ValueError(f"unknown mesh {mesh!r}")
+        if recurrent:
+            raise NotImplementedError("ModernUNet(recurrent=True) is not built")
+        activation = _resolve_activation(activation)
+        if not isinstance(activation, nn.GELU):
+            raise NotImplementedError("ModernUNet: only GELU is wired to the fused kernels")
+        self.context_size = int(context_size)
+        self.mesh = mesh
+        hidden_channels = [int(c) for c in hidden_channels]
+        if (2 * hidden_channels[0]) % 8:
+            raise ValueError("final GroupNorm(8, 2 * hidden_channels[0]) needs hidden_channels[0] % 4 == 0 (unet.py:739)")
+        in_channels = constant_channels + (prescribed_channels + prognostic_channels) * context_size
+        self.encoder = _ModernUNetEncoder(in_channels, hidden_channels, mesh=None)
+        self.middle = MiddleBlock(in_channels=hidden_channels[-1], norm=norm, activation=activation, mesh=None)
+        self.decoder = _ModernUNetDecoder(hidden_channels, prognostic_channels, activation, mesh=None)
+
+    def one_step(self, x):
+        return self.decoder(self.middle(self.encoder(x)))
+
+
 class _ConvLSTMCell(nn.Module):
-    def __init__(self, input_size, hidden_size, bias=True):
+    def __init__(self, input_size, hidden_size, bias=True, mesh="equirectangular"):
         super().__init__()
         self.hidden_size = hidden_size
-        self.conv = nn.Sequential(CylinderPad(1), nn.Conv2d(input_size + hidden_size, hidden_size * 4, kernel_size=3,
-                                                            stride=1, padding=0, bias=bias))
+        if mesh == "healpix":   # convlstm.py:56-63: state-dict key conv.layers.1.*
+            self.conv = HEALPixLayer(layer=nn.Conv2d, in_channels=input_size + hidden_size, out_channels=hidden_size * 4,
+                                     kernel_size=3, padding=1, bias=bias)
+        else:
+            self.conv = nn.Sequential(CylinderPad(1), nn.Conv2d(input_size + hidden_size, hidden_size * 4, kernel_size=3,
+                                                                stride=1, padding=0, bias=bias))
+
+    def gates(self, x, h_prev):
+        """conv3x3(cat(x, h_prev)) without the cat (convlstm.py:94)."""
+        if isinstance(self.conv, HEALPixLayer):
+            return self.conv(x, 0, x1=h_prev)
+        conv = self.conv[1]
+        return ops.conv3x3_cyl(x, conv.weight, conv.bias, 0, x1=h_prev)
 
 
 class ConvLSTM(HipBackbone):
+    """reference models/convlstm/convlstm.py:114-251.  The loop runs from t = 0 (teacher forcing while
+    t < context_size) because the LSTM state is carried from the first frame on; there is therefore no ranged
+    `rollout_into` -- a sharded evaluation collects its trajectory after the whole rollout (sharding.py)."""
+
     def __init__(self, batch_size: int = 16, constant_channels: int = 4, prescribed_channels: int = 0,
                  prognostic_channels: int = 1, hidden_sizes: list = [16, 16], height: int = 32, width: int = 64,
                  device=None, bias: bool = True, context_size: int = 1, mesh: str = "equirectangular", **kwargs):
         super().__init__()
-        if mesh != "equirectangular":
-            raise NotImplementedError("HEALPix variant is a 'next' row (SURVEY.md 8f f3)")
+        if mesh not in ("equirectangular", "healpix"):
+            raise ValueError(f"unknown mesh {mesh!r}")
+        self.mesh = mesh
         self.hidden_sizes = list(hidden_sizes)
         self.context_size = int(context_size)
         in_size = constant_channels + prescribed_channels + prognostic_channels
         h0 = self.hidden_sizes[0]
-        self.encoder = nn.Sequential(
-            CylinderPad(1), nn.Conv2d(in_size, h0, kernel_size=3, padding=0), nn.Tanh(),
-            CylinderPad(1), nn.Conv2d(h0, h0, kernel_size=3, padding=0), nn.Tanh(),
-            CylinderPad(1), nn.Conv2d(h0, h0, kernel_size=3, padding=0))
-        self.clstm = nn.Sequential(*[_ConvLSTMCell(hs, hs, bias) for hs in self.hidden_sizes])
-        self.decoder = nn.Sequential(CylinderPad(1), nn.Conv2d(self.hidden_sizes[-1], prognostic_channels, kernel_size=3,
-                                                               padding=0))
+        if mesh == "healpix":   # convlstm.py:155-161, :186-193
+            hpx = lambda ci, co: HEALPixLayer(layer=nn.Conv2d, in_channels=ci, out_channels=co, kernel_size=3, padding=1)
+            self.encoder = nn.Sequential(hpx(in_size, h0), nn.Tanh(), hpx(h0, h0), nn.Tanh(), hpx(h0, h0))
+            self.decoder = hpx(self.hidden_sizes[-1], prognostic_channels)
+        else:
+            self.encoder = nn.Sequential(
+                CylinderPad(1), nn.Conv2d(in_size, h0, kernel_size=3, padding=0), nn.Tanh(),
+                CylinderPad(1), nn.Conv2d(h0, h0, kernel_size=3, padding=0), nn.Tanh(),
+                CylinderPad(1), nn.Conv2d(h0, h0, kernel_size=3, padding=0))
+            self.decoder = nn.Sequential(CylinderPad(1), nn.Conv2d(self.hidden_sizes[-1], prognostic_channels,
+                                                                   kernel_size=3, padding=0))
+        self.clstm = nn.Sequential(*[_ConvLSTMCell(hs, hs, bias, mesh) for hs in self.hidden_sizes])
+
+    def _decode(self, x):
+        return self.decoder(x) if isinstance(self.decoder, HEALPixLayer) else _run_stack(self.decoder, x)
+
+    def _rollout(self, constants, prescribed, prognostic):
+        """convlstm.py:210-251 on [N, T, C, H, W] tensors (N = batch, or batch * 12 faces): loop from t = 0, teacher
+        forcing while t < context_size, (h, c) carried across steps, outputs[context_size:] returned.  The states
+        live in local tensors instead of module attributes (:108-109), so the module is re-entrant."""
+        b, t_total, cg, hgt, wid = prognostic.shape
+        ctx = self.context_size
+        if t_total <= ctx:
+            raise _lib.DlwpError(f"need more than context_size={ctx} frames, got {t_total}")
+        dev = prognostic.device
+        hs = [torch.zeros(b, n, hgt, wid, device=dev) for n in self.hidden_sizes]
+        cs = [torch.zeros(b, n, hgt, wid, device=dev) for n in self.hidden_sizes]
+        out = torch.empty(b, t_total - ctx, cg, hgt, wid, device=dev, dtype=torch.float32)
+        prev = None
+        for t in range(t_total):
+            prog_t = prognostic[:, t] if t < ctx else prev
+            parts = []
+            if constants is not None:
+                parts.append(constants[:, 0])
+            if prescribed is not None:
+                parts.append(prescribed[:, t])
+            parts.append(prog_t)
+            x = _run_stack(self.encoder, torch.cat(parts, dim=1))
+            for i, cell in enumerate(self.clstm):
+                hs[i], cs[i] = ops.convlstm_gates(cell.gates(x, hs[i]), cs[i])
+                x = hs[i]
+            inc = self._decode(x)
+            if t >= ctx:
+                torch.add(prog_t, inc, out=out[:, t - ctx])
+                prev = out[:, t - ctx]
+            else:
+                prev = prog_t + inc
+        return out
 
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
-        """convlstm.py:210-251: loop from t = 0, teacher forcing while t < context_size, (h, c) carried
-        across steps, outputs[context_size:] returned.  The states live in local tensors instead of
-        module attributes (:108-109), so the module is re-entrant."""
         constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
         with torch.no_grad():
-            b, t_total, cg, hgt, wid = prognostic.shape
-            ctx = self.context_size
-            if t_total <= ctx:
-                raise _lib.DlwpError(f"need more than context_size={ctx} frames, got {t_total}")
-            dev = prognostic.device
-            hs = [torch.zeros(b, n, hgt, wid, device=dev) for n in self.hidden_sizes]
-            cs = [torch.zeros(b, n, hgt, wid, device=dev) for n in self.hidden_sizes]
-            out = torch.empty(b, t_total - ctx, cg, hgt, wid, device=dev, dtype=torch.float32)
-            prev = None
-            for t in range(t_total):
-                prog_t = prognostic[:, t] if t < ctx else prev
-                parts = []
-                if constants is not None:
-                    parts.append(constants[:, 0])
-                if prescribed is not None:
-                    parts.append(prescribed[:, t])
-                parts.append(prog_t)
-                x = _run_stack(self.encoder, torch.cat(parts, dim=1))
-                for i, cell in enumerate(self.clstm):
-                    conv = cell.conv[1]
-                    gates = ops.conv3x3_cyl(x, conv.weight, conv.bias, 0, x1=hs[i])
-                    hs[i], cs[i] = ops.convlstm_gates(gates, cs[i])
-                    x = hs[i]
-                inc = _run_stack(self.decoder, x)
-                if t >= ctx:
-                    torch.add(prog_t, inc, out=out[:, t - ctx])
-                    prev = out[:, t - ctx]
-                else:
-                    prev = prog_t + inc
-            return out
+            return self._rollout(constants, prescribed, prognostic)
+
+
+class ConvLSTMHPX(ConvLSTM):
+    """reference models/convlstm/convlstm.py:258-305: ConvLSTM on the HEALPix mesh.  Tensors carry a face axis
+    (constants [B, 1, C, 12, H, W], prescribed / prognostic [B, T, C, 12, H, W]); faces fold into the batch
+    (`_prepare_inputs` :293-305), every HEALPixLayer(Conv2d) is one dlwp_conv3x3_hpx_f32 launch with the Tanh in
+    its epilogue and `cat(x, h)` folded into its two-segment input."""
+
+    def __init__(self, batch_size: int = 16, constant_channels: int = 4, prescribed_channels: int = 0,
+                 prognostic_channels: int = 1, hidden_sizes: list = [16, 16], height: int = 32, width: int = 64,
+                 device=None, bias: bool = True, context_size: int = 1, mesh: str = "healpix", **kwargs):
+        super().__init__(batch_size=batch_size, constant_channels=constant_channels,
+                         prescribed_channels=prescribed_channels, prognostic_channels=prognostic_channels,
+                         hidden_sizes=hidden_sizes, height=height, width=width, device=device, bias=bias,
+                         context_size=context_size, mesh="healpix")
+
+    def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        for name, t in (("constants", constants), ("prescribed", prescribed), ("prognostic", prognostic)):
+            if t is not None:
+                _lib.require_cuda_tensor(t, name)
+                if t.dim() != 6 or t.shape[3] != 12:
+                    raise _lib.DlwpError(f"{name}: expected [B, T, C, 12, H, W], got {tuple(t.shape)}")
+        if prognostic is None:
+            raise _lib.DlwpError("prognostic is required")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training is a 'next' row (SURVEY.md 8f f4); call .eval() / no_grad()")
+        b, t_total, cg, f, h, w = prognostic.shape
+        with torch.no_grad():
+            fold5 = lambda t: t.permute(0, 3, 1, 2, 4, 5).reshape(b * f, t.shape[1], t.shape[2], h, w).float().contiguous()
+            out = self._rollout(fold5(constants) if constants is not None else None,
+                                fold5(prescribed) if prescribed is not None else None, fold5(prognostic))
+            return out.reshape(b, f, out.shape[1], cg, h, w).permute(0, 2, 3, 1, 4, 5).contiguous()

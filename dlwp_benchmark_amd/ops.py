@@ -28,6 +28,7 @@ class WindowSpec:
     heads: int
     head_dim: int
     scale: float
+    form: int = -1          # dlwp_window_attn_f32: -1 by window size, 0 fp32 MFMA, 1 bf16x6 (struct dlwp_wattn_desc.form)
 
     def to_c(self) -> "_lib.WAttnDesc":
         d = _lib.WAttnDesc()
@@ -38,14 +39,18 @@ class WindowSpec:
         d.use_mask = int(self.use_mask)
         d.bias_mode = int(self.bias_mode)
         d.heads, d.head_dim, d.scale = int(self.heads), int(self.head_dim), float(self.scale)
+        d.form = int(self.form)
         return d
 
 
 def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table: torch.Tensor,
                      spec: WindowSpec, precision: str = "fp32") -> torch.Tensor:
     """qkv [B, L, 3*C] (qkv Linear output, un-padded token order) -> [B, L, C].
-    precision "fp32": exact fp32 products (parity path); "bf16": bf16 MFMA operands, fp32 accumulate."""
-    if precision not in ("fp32", "bf16"):
+    precision "fp32": fp32-accurate products (parity path; the form of the contractions by window size),
+    "fp32_mfma" / "bf16x6": the same with the form forced (each is the other's cross-check);
+    "bf16": bf16 MFMA operands, fp32 accumulate."""
+    forms = {"fp32": spec.form, "fp32_mfma": 0, "bf16x6": 1, "bf16": -1}
+    if precision not in forms:
         raise _lib.DlwpError(f"unknown attention precision {precision!r}")
     _lib.require_cuda_tensor(qkv, "qkv")
     _lib.require_cuda_tensor(table, "bias table")
@@ -59,11 +64,13 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table:
     out = torch.empty(b, l, c, device=qkv.device, dtype=torch.float32)
     lib = _lib.load()
     d = spec.to_c()
+    d.form = forms[precision]
     with torch.cuda.device(qkv.device):
         fn = lib.dlwp_window_attn_bf16 if precision == "bf16" else lib.dlwp_window_attn_f32
         _lib.check(fn(ctypes.byref(d), qkv.data_ptr(),
                       qkv_bias.contiguous().data_ptr() if qkv_bias is not None else None,
-                      table.data_ptr(), out.data_ptr(), b, _lib.stream_ptr()), "dlwp_window_attn_" + precision)
+                      table.data_ptr(), out.data_ptr(), b, _lib.stream_ptr()),
+                   "dlwp_window_attn_" + ("bf16" if precision == "bf16" else "f32"))
     return out
 
 

@@ -7,7 +7,10 @@ exchange is collecting the trajectories ([B/N, K, Cg, H, W] per rank) for the ev
 (reference scripts/evaluate.py:243 `outputs.append(output.cpu())`): ONE all-gather per rollout
 over RCCL/xGMI.  It is issued per time chunk with async_op=True -- ProcessGroupNCCL runs it on its
 own HIP stream after the chunk's kernels -- so the transfer of chunk k overlaps the compute of
-chunk k+1 and only the last chunk's gather is exposed.
+chunk k+1 and only the last chunk's gather is exposed.  Exception: a backbone whose rollout is a
+persistent launch that needs EVERY compute unit resident at once (FNO2DModule, `exclusive_launch`)
+must not share the chip with an RCCL kernel -- its workgroups spin on peers that the collective's
+workgroups would keep off the chip -- so there the whole rollout runs first and the gather follows it.
 
 Works with any process group backend (`gloo` in the CPU tests); with world_size == 1 it is the
 plain device-resident rollout.
@@ -37,9 +40,10 @@ def chunk_bounds(n_steps: int, chunks: int, min_len: int = 1):
 
 class ShardedRollout:
     """Callable: runs `model`'s rollout on this rank's shard and returns the gathered global
-    trajectory [world*B_local, K, Cg, H, W] (rank-major).  `model` must provide
-    `rollout_into(out, constants, prescribed, prognostic, step_begin, step_end)`, `_check_inputs`
-    and `context_size` (every dlwp_benchmark_amd backbone does)."""
+    trajectory [world*B_local, K, Cg, H, W] (rank-major).  `model` must provide `_check_inputs`, `context_size`
+    and either `rollout_into(out, constants, prescribed, prognostic, step_begin, step_end)` (FNO, Swin, Pangu,
+    FourCastNet, U-Net: chunked, overlapped gather) or only `forward` (ConvLSTM, whose recurrent state rules out a
+    ranged rollout: one gather after the rollout)."""
 
     def __init__(self, model, world_size: int = 1, rank: int = 0, chunks: int = 4, group=None, gather: bool = True):
         self.model = model
@@ -60,11 +64,25 @@ class ShardedRollout:
         k = t - ctx
         with torch.no_grad():
             local = torch.empty(b, k, cg, h, w, device=prognostic.device, dtype=prognostic.dtype)
+            ranged = hasattr(m, "rollout_into")
             if self.world == 1 or not self.gather:
+                if not ranged:
+                    return m(constants=constants, prescribed=prescribed, prognostic=prognostic)
                 m.rollout_into(local, constants, prescribed, prognostic, 0, k)
                 return local
             import torch.distributed as dist
 
+            if not ranged or getattr(m, "exclusive_launch", False):
+                # no collective beside the rollout: run it whole, then ONE all-gather of the trajectory
+                if ranged:
+                    m.rollout_into(local, constants, prescribed, prognostic, 0, k)
+                else:
+                    local = m(constants=constants, prescribed=prescribed, prognostic=prognostic)
+                host = local.is_cuda and dist.get_backend(self.group) != "nccl"
+                send = local.cpu() if host else local.contiguous()
+                recv = torch.empty((self.world * b,) + tuple(send.shape[1:]), device=send.device, dtype=send.dtype)
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+                return recv.to(prognostic.device) if host else recv
             bounds = chunk_bounds(k, self.chunks)
             works, parts = [], []
             # a CPU-only backend (gloo rehearsal on a one-GPU box) cannot move device tensors: stage on the host

@@ -32,7 +32,8 @@ typedef enum dlwp_status {
   DLWP_ERR_INVALID_ARGUMENT = -1,
   DLWP_ERR_UNSUPPORTED = -2,
   DLWP_ERR_HIP = -3,
-  DLWP_ERR_WORKSPACE = -4
+  DLWP_ERR_WORKSPACE = -4,
+  DLWP_ERR_TIMEOUT = -5      /* a fused kernel's inter-workgroup hand-off exceeded its spin bound (output poisoned) */
 } dlwp_status;
 
 /* library version, major*10000 + minor*100 + patch */
@@ -41,13 +42,6 @@ int32_t dlwp_version(void);
 const char* dlwp_last_error(void);
 /* number of visible HIP devices (<0 on error); does not create a context */
 int32_t dlwp_device_count(void);
-
-/* The channel-MLP GEMMs of the FNO path run by default as "bf16x6": each fp32 operand is split
- * exactly into three bf16 parts and the six significant cross products are accumulated in fp32 on the
- * bf16 matrix pipe (fp32-GEMM accuracy).  on != 0 selects the plain fp32 MFMA
- * kernels instead (A/B measurements, numerical cross-check).  Process-wide; returns the previous
- * setting.  Environment: DLWP_FP32_MFMA=1 has the same effect. */
-int32_t dlwp_set_fp32_mfma(int32_t on);
 
 /* ------------------------------------------------------------------------------------------
  * FNO2d rollout  (reference models/fno/fno.py:12-106 `FNO2DModule`; the arithmetic it delegates
@@ -81,12 +75,30 @@ typedef struct dlwp_fno2d_desc {
   const float* proj_b1;        /* [projection]                                              */
   const float* proj_w2;        /* [out, projection]                                         */
   const float* proj_b2;        /* [out]                                                     */
+  /* ---- execution form, fixed for the life of the plan (no process-wide switches exist) ---- */
+  int32_t precision_form;      /* 0 (default): the fp32 channel GEMMs run as "bf16x6" -- each fp32 operand split exactly
+                                  into three bf16 parts, the six significant cross products accumulated in fp32 on the
+                                  bf16 matrix pipe (fp32-GEMM accuracy) -- and the fused kernels;
+                                  1: plain fp32-MFMA kernels and the unfused spectral path (independent cross-check) */
+  int32_t launch_form;         /* 0 (default): fewest launches the shapes allow (whole rollout range in one persistent
+                                  launch); 1: one launch per step; 2: three launches per step; 3: unfused kernels */
+  int32_t on_timeout;          /* a fused launch whose hand-off spin ran out: 0 (default) re-run the range on the unfused
+                                  kernels (no hand-offs) and return DLWP_OK; 1 return DLWP_ERR_TIMEOUT */
+  int32_t unchecked;           /* 0 (default): every call that used fused kernels synchronises `stream` once and reads
+                                  their fail word; 1: fully asynchronous calls, the caller polls dlwp_fno2d_status */
+  int32_t debug_spin_limit;    /* 0: default bound (~0.1 s); > 0: spin bound of the hand-offs (test hook) */
 } dlwp_fno2d_desc;
 
 int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** plan, const dlwp_fno2d_desc* desc, void* stream);
 int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan);
 /* bytes of device workspace one call needs for `batch` samples */
 size_t dlwp_fno2d_workspace_bytes(const dlwp_fno2d_plan* plan, int32_t batch);
+/* Synchronises `stream` and reports whether a fused launch enqueued on it since the last call's start timed out
+ * (DLWP_ERR_TIMEOUT, outputs poisoned with NaN) -- for plans created with unchecked = 1. */
+int32_t dlwp_fno2d_status(const dlwp_fno2d_plan* plan, int32_t batch, void* workspace_dev, size_t workspace_bytes,
+                          void* stream);
+/* statistics: fused launches of this plan that timed out so far (re-run or reported) */
+uint32_t dlwp_fno2d_timeouts(const dlwp_fno2d_plan* plan);
 
 /* One backbone step WITHOUT the residual: y = fno(x).  Replaces `self.fno(x_t)` at fno.py:103.
  * x_dev [B, in, H, W], y_dev [B, out, H, W], both contiguous fp32. */
@@ -193,14 +205,14 @@ typedef struct dlwp_wattn_desc {
   int32_t bias_mode;      /* 0 Swin relative position, 1 Pangu earth-specific                  */
   int32_t heads, head_dim;
   float scale;            /* qk scale (head_dim ** -0.5 unless overridden)                     */
+  int32_t form;           /* dlwp_window_attn_f32 only: -1 by window size (default), 0 fp32 MFMA, 1 bf16x6 */
 } dlwp_wattn_desc;
 
 /* fp32-accurate window attention (the parity path), in one of two independent forms of the two contractions:
  * fp32 operands on v_mfma_f32_16x16x4_f32, or exact three-way bf16 splits of Q, K, V and P with six cross products each
- * on the bf16 matrix pipe ("bf16x6").  dlwp_set_window_attn_bf16x6(mode): 0 fp32 MFMA, 1 bf16x6, -1 (default) by window
- * size as measured (>= 512 tokens per window: fp32 MFMA, same time; smaller: bf16x6, faster); returns the previous mode;
- * env DLWP_WATTN_BF16X6 sets the initial one.  tokens * 3 * heads * head_dim must stay below 2^31. */
-int32_t dlwp_set_window_attn_bf16x6(int32_t mode);
+ * on the bf16 matrix pipe ("bf16x6").  desc->form selects: 0 fp32 MFMA, 1 bf16x6, -1 by window size as measured
+ * (>= 512 tokens per window: fp32 MFMA; smaller: bf16x6).  No process-wide switch exists.
+ * tokens * 3 * heads * head_dim must stay below 2^31. */
 int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* desc, const float* qkv_dev,
                              const float* qkv_bias_dev, const float* table_dev, float* out_dev,
                              int32_t batch, void* stream);

@@ -221,6 +221,12 @@ HPX_MUNET_CASES = {
 }
 
 
+HPX_CONVLSTM_CASES = {
+    "convlstmhpx_h8_8x8": (dict(batch_size=2, constant_channels=2, prescribed_channels=1, prognostic_channels=3,
+                                hidden_sizes=[8, 8], height=8, width=8, bias=True, context_size=2), (2, 5), (8, 8)),
+}
+
+
 def hpx_inputs(tag, cfg, batch, frames, hw):
     h, w = hw
     cc, cp, cg = cfg["constant_channels"], cfg["prescribed_channels"], cfg["prognostic_channels"]
@@ -259,6 +265,17 @@ def gen_hpx(ref):
         sha = W.fill_state_dict(m, gain=1.0)   # the reference zero-initialises conv2 / output_layer: fill everything
         constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
         with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):   # the reference forward prints shapes
+            y = m(constants=constants, prescribed=prescribed, prognostic=prognostic)
+        spec = [(k, list(v.shape)) for k, v in m.named_parameters()]
+        full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]
+        _save(f"model_{tag}", y=y.numpy().astype(np.float32), sha=np.array(sha), param_spec=np.array(json.dumps(spec)),
+              state_spec=np.array(json.dumps(full)))
+    for tag, (cfg, (batch, frames), hw) in HPX_CONVLSTM_CASES.items():
+        m = ref["convlstm"].ConvLSTMHPX(**cfg)
+        m.eval()
+        sha = W.fill_state_dict(m, gain=1.0)
+        constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
+        with torch.no_grad():
             y = m(constants=constants, prescribed=prescribed, prognostic=prognostic)
         spec = [(k, list(v.shape)) for k, v in m.named_parameters()]
         full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]

@@ -176,3 +176,39 @@ def munet_hpx_one_step(sd, cfg, x):
 def munet_hpx_rollout(sd, cfg, constants, prescribed, prognostic):
     """ModernUNet.forward (unet.py:139-203) with MUNetHPX._prepare_inputs (:234-269)."""
     return _hpx_rollout(lambda x: munet_hpx_one_step(sd, cfg, x), cfg, constants, prescribed, prognostic)
+
+
+def convlstm_hpx_rollout(sd, cfg, constants, prescribed, prognostic):
+    """reference models/convlstm/convlstm.py:210-251 with mesh="healpix" (ConvLSTMHPX :258-305): tensors
+    [B, T, C, 12, H, W], faces folded into the batch per step (:293-305), every convolution behind HEALPixPadding(1)
+    (utils/healpix.py:69-114), LSTM state carried from t = 0, teacher forcing while t < context_size."""
+    hidden = list(cfg["hidden_sizes"])
+    ctx = cfg["context_size"]
+    b, t_total, cg, f, hgt, wid = prognostic.shape
+    fold = lambda t: t.permute(0, 2, 1, 3, 4).reshape(b * f, t.shape[1], hgt, wid)    # "b c f h w -> (b f) c h w"
+    hs = [torch.zeros(b * f, n, hgt, wid) for n in hidden]
+    cs = [torch.zeros(b * f, n, hgt, wid) for n in hidden]
+    conv = lambda x, name: F.conv2d(healpix_pad(x, 1), sd[name + ".layers.1.weight"], sd.get(name + ".layers.1.bias"))
+    outs = []
+    for t in range(t_total):
+        prog_t = prognostic[:, t] if t < ctx else outs[-1]
+        parts = []
+        if constants is not None:
+            parts.append(fold(constants[:, 0]))
+        if prescribed is not None:
+            parts.append(fold(prescribed[:, t]))
+        parts.append(fold(prog_t))
+        x = torch.cat(parts, dim=1)
+        x = torch.tanh(conv(x, "encoder.0"))
+        x = torch.tanh(conv(x, "encoder.2"))
+        x = conv(x, "encoder.4")
+        for i, n in enumerate(hidden):
+            g = conv(torch.cat((x, hs[i]), dim=1), f"clstm.{i}.conv")
+            netin, ig, fg, og = torch.split(g, n, dim=1)
+            cs[i] = torch.sigmoid(fg) * cs[i] + torch.sigmoid(ig) * torch.tanh(netin)
+            hs[i] = torch.sigmoid(og) * torch.tanh(cs[i])
+            x = hs[i]
+        out = conv(x, "decoder")
+        out = out.reshape(b, f, cg, hgt, wid).permute(0, 2, 1, 3, 4)                  # "(b f) c h w -> b c f h w"
+        outs.append(prog_t + out)
+    return torch.stack(outs[ctx:], dim=1)

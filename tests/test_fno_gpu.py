@@ -154,20 +154,16 @@ def test_bf16x6_matches_fp32_mfma_kernels():
     """The default MLP kernels compute fp32 GEMMs as six bf16 MFMAs (bf16x6 split, fp32 accumulate);
     the plain fp32-MFMA kernels are the cross-check: both must agree with each other far below the
     parity tolerance, and both with the oracle."""
-    from dlwp_benchmark_amd import lib as L
     from dlwp_benchmark_amd.synthetic import navier_stokes
 
     ref, hip = _make_pair(**NS_KW)
     _, _, prog = navier_stokes(4, 6)
     p = prog.to(_dev())
-    lib = L.load()
-    prev = lib.dlwp_set_fp32_mfma(0)
-    try:
-        a = hip(prognostic=p)
-        lib.dlwp_set_fp32_mfma(1)
-        b = hip(prognostic=p)
-    finally:
-        lib.dlwp_set_fp32_mfma(prev)
+    a = hip(prognostic=p)
+    hip.set_execution_form(precision_form="fp32_mfma")     # a field of the plan descriptor, not a process-wide switch
+    b = hip(prognostic=p)
+    hip.set_execution_form(precision_form="bf16x6")
+    assert not torch.equal(a, b), "both forms bit-identical: is precision_form wired to the plan?"
     torch.cuda.synchronize()
     with torch.no_grad():
         want = ref(prognostic=prog)
@@ -233,3 +229,67 @@ def test_fno_persistent_rollout_is_bit_reproducible():
         assert bool(torch.isfinite(ref).all())
         for _ in range(60):
             assert torch.equal(hip(prognostic=prog), ref)
+
+
+def test_fused_timeout_is_loud_and_falls_back():
+    """A fused launch whose hand-off spin runs out must never return silently poisoned output: the kernel
+    sets a fail word beside the NaN poison, the host reads it after the launch and either raises DLWP_ERR_TIMEOUT
+    (on_timeout="raise") or re-runs the range on the unfused kernels, which have no hand-offs (default).  The timeout
+    is forced through the descriptor's debug_spin_limit (one poll): run ONCE."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    ref, hip = _make_pair(**NS_KW)
+    _, _, prog = navier_stokes(32, 4)        # 32 samples x 8 workgroups = the whole chip, three steps
+    p = prog.to(_dev())
+    with torch.no_grad():
+        want = ref(prognostic=prog)
+    good = hip(prognostic=p)
+    assert hip.fused_timeouts() == 0
+    assert max(per_step_rel_l2(good, want)) <= TOL
+    hip._debug_spin_limit = 1
+    hip.set_execution_form(on_timeout="raise")
+    with pytest.raises(L.DlwpError, match="status -5"):
+        hip(prognostic=p)
+    assert hip.fused_timeouts() == 1
+    hip.set_execution_form(on_timeout="rerun")   # new plan (the form is part of the plan key)
+    got = hip(prognostic=p)
+    torch.cuda.synchronize()
+    assert hip.fused_timeouts() == 1, "the forced timeout did not fire"
+    assert torch.isfinite(got).all()
+    assert max(per_step_rel_l2(got, want)) <= TOL
+    hip._debug_spin_limit = 0
+    again = hip(prognostic=p)
+    assert hip.fused_timeouts() == 0 and torch.equal(again, good)
+
+
+def test_tfno_matches_fno_with_reconstructed_weights():
+    """TFNO2DModule (fno.py:109-146) = the FNO path on the dense weight rebuilt from its Tucker factors: same
+    trajectory as an FNO2DModule loaded with the reconstructed tensors, and as the oracle on them."""
+    from dlwp_benchmark_amd.models import FNO2DModule, TFNO2DModule
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+    from dlwp_benchmark_amd.weights import fill_state_dict
+    from oracle.restate.fno import FNO2DModuleRef
+
+    kw = dict(NS_KW)
+    t = TFNO2DModule(rank=0.8, **kw)
+    fill_state_dict(t, std_fn=lambda n, s: 0.3 if ("core" in n or "factor" in n) else None, gain=0.85)
+    with torch.no_grad():   # scale every core so that the dense weight has the magnitude the FNO tests use
+        for w in t.fno.fno_blocks.convs.weight:
+            w.core.mul_(0.85 / 32 ** 0.5 / float(w.dense().abs().pow(2).mean().sqrt()))
+    dense = FNO2DModule(**kw)
+    sd = {k: v for k, v in t.state_dict().items() if ".core" not in k and ".factors." not in k}
+    for l, w in enumerate(t.fno.fno_blocks.convs.weight):
+        sd[f"fno.fno_blocks.convs.weight.{l}.tensor"] = w.dense().detach()
+    dense.load_state_dict(sd)
+    ref = FNO2DModuleRef(**kw).eval()
+    ref.load_state_dict(sd)
+    _, _, prog = navier_stokes(2, 4)
+    with torch.no_grad():
+        want = ref(prognostic=prog)
+    a = t.to(_dev()).eval()(prognostic=prog.to(_dev()))
+    b = dense.to(_dev()).eval()(prognostic=prog.to(_dev()))
+    # the module rebuilds the dense weight on the device, the cross-check used the host: equal up to that rounding
+    assert max(per_step_rel_l2(a, b)) <= 1e-6
+    assert max(per_step_rel_l2(a, want)) <= TOL
+    assert max(per_step_rel_l2(b, want)) <= TOL

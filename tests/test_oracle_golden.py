@@ -75,7 +75,8 @@ def test_backbone_restatement_matches_reference(tag):
 # HEALPix (8f f3): face padding + HEALPix U-Net restatements vs the real reference
 # ------------------------------------------------------------------------------------------
 from dlwp_benchmark_amd import weights as W
-from oracle.make_golden import HPX_MODEL_CASES, HPX_MUNET_CASES, HPX_PAD_CASES, HPX_SWIN_CASES, hpx_inputs
+from oracle.make_golden import (HPX_CONVLSTM_CASES, HPX_MODEL_CASES, HPX_MUNET_CASES, HPX_PAD_CASES, HPX_SWIN_CASES,
+                                hpx_inputs)
 from oracle.restate import healpix as R_hpx
 
 
@@ -127,6 +128,21 @@ def test_munet_hpx_restatement_matches_reference(tag):
     constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
     with torch.no_grad():
         y = R_hpx.munet_hpx_rollout(sd, cfg, constants, prescribed, prognostic)
+    ref = torch.from_numpy(g["y"])
+    assert y.shape == ref.shape
+    assert max(rel_l2(y[:, t], ref[:, t]) for t in range(ref.shape[1])) < 1e-6
+
+
+@pytest.mark.parametrize("tag", list(HPX_CONVLSTM_CASES))
+def test_convlstm_hpx_restatement_matches_reference(tag):
+    """ConvLSTMHPX (convlstm.py:258-305) vs the trajectory of the real class."""
+    cfg, (batch, frames), hw = HPX_CONVLSTM_CASES[tag]
+    g = load_golden(f"model_{tag}")
+    sd, sha = fill_by_spec(json.loads(str(g["param_spec"])), gain=1.0)
+    assert sha == str(g["sha"]), "filler drifted: regenerate fixtures"
+    constants, prescribed, prognostic = hpx_inputs(tag, cfg, batch, frames, hw)
+    with torch.no_grad():
+        y = R_hpx.convlstm_hpx_rollout(sd, cfg, constants, prescribed, prognostic)
     ref = torch.from_numpy(g["y"])
     assert y.shape == ref.shape
     assert max(rel_l2(y[:, t], ref[:, t]) for t in range(ref.shape[1])) < 1e-6

@@ -36,14 +36,32 @@ def _inputs(b, t):
     return torch.randn(b, t, 1, 8, 16, generator=g), torch.randn(b, t, 2, 8, 16, generator=g)
 
 
-def _worker(rank, world, port, ret):
+class ExclusiveBackbone(ToyBackbone):
+    """like FNO2DModule: the rollout is a launch that needs the whole chip -- no collective may run beside it"""
+    exclusive_launch = True
+
+
+class ForwardOnlyBackbone:
+    """like ConvLSTM: recurrent state, no ranged rollout_into"""
+    context_size = 1
+    _check_inputs = ToyBackbone._check_inputs
+
+    def __call__(self, constants=None, prescribed=None, prognostic=None):
+        out = torch.empty(prognostic.shape[0], prognostic.shape[1] - 1, *prognostic.shape[2:])
+        return ToyBackbone().rollout_into(out, constants, prescribed, prognostic)
+
+
+BACKBONES = {"toy": ToyBackbone, "exclusive": ExclusiveBackbone, "forward_only": ForwardOnlyBackbone}
+
+
+def _worker(rank, world, port, ret, kind="toy"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         presc, prog = _inputs(6, 8)
         lo, hi = shard_bounds(6, world, rank)
-        run = ShardedRollout(ToyBackbone(), world_size=world, rank=rank, chunks=3)
+        run = ShardedRollout(BACKBONES[kind](), world_size=world, rank=rank, chunks=3)
         out = run(prescribed=presc[lo:hi].contiguous(), prognostic=prog[lo:hi].contiguous())
         ret[rank] = out
     finally:
@@ -61,12 +79,15 @@ def test_shard_bounds_cover_everything():
 
 
 @pytest.mark.timeout(120)
-def test_two_rank_gather_matches_single_process():
+@pytest.mark.parametrize("kind", list(BACKBONES))
+def test_two_rank_gather_matches_single_process(kind):
+    """chunked overlapped gather (toy), rollout-then-gather for a backbone that needs the chip to itself (exclusive),
+    and for one without a ranged rollout (forward_only)"""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + 3 * list(BACKBONES).index(kind)
+    mp.spawn(_worker, args=(world, port, ret, kind), nprocs=world, join=True)
     presc, prog = _inputs(6, 8)
     want = ShardedRollout(ToyBackbone(), world_size=1)(prescribed=presc, prognostic=prog)
     for r in range(world):
