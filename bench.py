@@ -162,7 +162,7 @@ def _golden_inputs(cfg, batch, frames):
 def _attn_tag(name, a):
     if name.startswith("dlwp_window_attn"):
         d = a[0]._obj
-        return (tuple(d.padded), tuple(d.window), int(d.heads), int(d.head_dim), int(a[5]), int(d.use_mask))
+        return (tuple(d.padded), tuple(d.window), int(d.heads), int(d.head_dim), int(a[5]), int(d.use_mask))   # a[5] = batch
     return None
 
 

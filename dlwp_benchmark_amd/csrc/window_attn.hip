@@ -493,6 +493,13 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const Desc D, const fl
 }  // namespace wattn
 }  // namespace dlwp
 
+namespace dlwp {   // window_attn2.hip: the 2-D (Swin) fast path
+size_t wattn2_workspace_bytes(const dlwp_wattn_desc* u, int batch, int np);
+int32_t wattn2_run(const dlwp_wattn_desc* u, const float* qkv, const float* table, float* out, int batch, void* workspace,
+                   size_t workspace_bytes, hipStream_t s, int np);
+const int* wattn2_fallback_counter(const dlwp_wattn_desc* u, int batch, int np, const void* workspace);
+}
+
 using namespace dlwp;
 using namespace dlwp::wattn;
 
@@ -596,18 +603,47 @@ static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, cons
   return fail(DLWP_ERR_UNSUPPORTED, "head_dim %d not supported", D.d);
 }
 
+extern "C" size_t dlwp_window_attn_workspace_bytes(const dlwp_wattn_desc* u, int32_t batch, int32_t bf16) {
+  if (!u || batch <= 0) return 0;
+  if (!bf16 && u->form == 0) return 0;     // the fp32-MFMA form is the generic kernel
+  return wattn2_workspace_bytes(u, batch, bf16 ? 1 : 3);
+}
+
+extern "C" int32_t dlwp_window_attn_fallbacks(const dlwp_wattn_desc* u, int32_t batch, int32_t bf16, const void* workspace,
+                                              void* stream, int32_t* count) {
+  DLWP_REQUIRE(u && count, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  *count = 0;
+  const int* dev = wattn2_fallback_counter(u, batch, bf16 ? 1 : 3, workspace);
+  if (!dev) return DLWP_OK;   // generic kernel: exact running maximum, no fallback exists
+  DLWP_HIP_CHECK(hipMemcpyAsync(count, dev, sizeof(int32_t), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
+  DLWP_HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  return DLWP_OK;
+}
+
 extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
-                                        const float* table, float* out, int32_t batch, void* stream) {
+                                        const float* table, float* out, int32_t batch, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
   // fp32-accurate either way; desc->form picks the form of the two contractions: 0 fp32 MFMA, 1 bf16x6, -1 by window
   // size as measured (whole-map windows, >= 512 tokens: fp32 MFMA; small windows: bf16x6).  Each is the other's cross-check.
   DLWP_REQUIRE(u, DLWP_ERR_INVALID_ARGUMENT, "null descriptor");
   DLWP_REQUIRE(u->form >= -1 && u->form <= 1, DLWP_ERR_INVALID_ARGUMENT, "form %d not in {-1, 0, 1}", u->form);
   const int n_win = u->window[0] * u->window[1] * u->window[2];
   const bool x6 = u->form > 0 || (u->form < 0 && n_win < 512);
+  if (u->form != 0 && qkv && table && out && batch > 0) {
+    // 2-D windows (every Swin block): the second-generation kernel (bf16x6 operands, bias through the accumulator,
+    // masked tiles skipped); returns 1 when the descriptor or the workspace does not fit -> generic kernel below
+    const int32_t rc = wattn2_run(u, qkv, table, out, batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 3);
+    if (rc != 1) return rc;
+  }
   return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, x6 ? 2 : 0);
 }
 
 extern "C" int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias,
-                                         const float* table, float* out, int32_t batch, void* stream) {
+                                         const float* table, float* out, int32_t batch, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (u && qkv && table && out && batch > 0) {
+    const int32_t rc = wattn2_run(u, qkv, table, out, batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 1);
+    if (rc != 1) return rc;
+  }
   return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, 1);
 }

@@ -67,8 +67,12 @@ SIGNATURES = {
     "dlwp_spectral_conv2d_set_weights_dev": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "dlwp_spectral_conv2d_plan_destroy": (c_int32, [c_void_p]),
     "dlwp_spectral_conv2d_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
-    "dlwp_window_attn_f32": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
-    "dlwp_window_attn_bf16": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "dlwp_window_attn_workspace_bytes": (c_size_t, [POINTER(WAttnDesc), c_int32, c_int32]),
+    "dlwp_window_attn_fallbacks": (c_int32, [POINTER(WAttnDesc), c_int32, c_int32, c_void_p, c_void_p, c_int32_p]),
+    "dlwp_window_attn_f32": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                       c_size_t, c_void_p]),
+    "dlwp_window_attn_bf16": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                        c_size_t, c_void_p]),
     "dlwp_afno2d_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "dlwp_afno2d_mix_scaled_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,

@@ -44,11 +44,13 @@ class WindowSpec:
 
 
 def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table: torch.Tensor,
-                     spec: WindowSpec, precision: str = "fp32") -> torch.Tensor:
+                     spec: WindowSpec, precision: str = "fp32", count_fallbacks: bool = False):
     """qkv [B, L, 3*C] (qkv Linear output, un-padded token order) -> [B, L, C].
     precision "fp32": fp32-accurate products (parity path; the form of the contractions by window size),
     "fp32_mfma" / "bf16x6": the same with the form forced (each is the other's cross-check);
-    "bf16": bf16 MFMA operands, fp32 accumulate."""
+    "bf16": bf16 MFMA operands, fp32 accumulate.
+    count_fallbacks=True (diagnostics, synchronises): returns (out, workgroups of the fast path that left the exponent
+    slack of their softmax offset and were recomputed with the exact row maximum)."""
     forms = {"fp32": spec.form, "fp32_mfma": 0, "bf16x6": 1, "bf16": -1}
     if precision not in forms:
         raise _lib.DlwpError(f"unknown attention precision {precision!r}")
@@ -66,11 +68,22 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table:
     d = spec.to_c()
     d.form = forms[precision]
     with torch.cuda.device(qkv.device):
-        fn = lib.dlwp_window_attn_bf16 if precision == "bf16" else lib.dlwp_window_attn_f32
+        bf16 = precision == "bf16"
+        fn = lib.dlwp_window_attn_bf16 if bf16 else lib.dlwp_window_attn_f32
+        # the caller (torch's caching allocator) owns the workspace of the fast path; 0 bytes = generic kernel
+        nbytes = int(lib.dlwp_window_attn_workspace_bytes(ctypes.byref(d), b, 1 if bf16 else 0))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device) if nbytes else None
         _lib.check(fn(ctypes.byref(d), qkv.data_ptr(),
                       qkv_bias.contiguous().data_ptr() if qkv_bias is not None else None,
-                      table.data_ptr(), out.data_ptr(), b, _lib.stream_ptr()),
+                      table.data_ptr(), out.data_ptr(), b, ws.data_ptr() if ws is not None else None, nbytes,
+                      _lib.stream_ptr()),
                    "dlwp_window_attn_" + ("bf16" if precision == "bf16" else "f32"))
+        if count_fallbacks:
+            n = ctypes.c_int32(0)
+            if ws is not None:
+                _lib.check(lib.dlwp_window_attn_fallbacks(ctypes.byref(d), b, 1 if bf16 else 0, ws.data_ptr(),
+                                                          _lib.stream_ptr(), ctypes.byref(n)), "dlwp_window_attn_fallbacks")
+            return out, int(n.value)
     return out
 
 

@@ -213,15 +213,27 @@ typedef struct dlwp_wattn_desc {
  * on the bf16 matrix pipe ("bf16x6").  desc->form selects: 0 fp32 MFMA, 1 bf16x6, -1 by window size as measured
  * (>= 512 tokens per window: fp32 MFMA; smaller: bf16x6).  No process-wide switch exists.
  * tokens * 3 * heads * head_dim must stay below 2^31. */
+/* bytes of device workspace the FAST path of the call below needs for this descriptor (bf16 != 0: for
+ * dlwp_window_attn_bf16); 0 when the descriptor runs on the generic kernel, which needs none.  The fast path covers
+ * 2-D windows (bias_mode 0, grid[0] = 1, no zero padding, window longitude extent a multiple of 16, head_dim a multiple
+ * of 8 but not of 32, region boundaries along longitude on multiples of 16): every Swin block of the reference.  Its
+ * workspace holds the window-ordered bf16 operand images a prep kernel writes per call.  Masked
+ * (shifted-window) tiles are skipped there: exact unless a masked logit exceeds its row's unmasked maximum by > 83. */
+size_t dlwp_window_attn_workspace_bytes(const dlwp_wattn_desc* desc, int32_t batch, int32_t bf16);
+/* Diagnostics (synchronises `stream`): workgroups of the LAST fast-path call on this workspace whose scores left the
+ * 2^+-100 exponent slack around their reference offset and were recomputed with the exact row maximum. */
+int32_t dlwp_window_attn_fallbacks(const dlwp_wattn_desc* desc, int32_t batch, int32_t bf16, const void* workspace_dev,
+                                   void* stream, int32_t* count);
+/* workspace_dev may be NULL (or smaller than the bytes above): the generic kernel runs instead. */
 int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* desc, const float* qkv_dev,
                              const float* qkv_bias_dev, const float* table_dev, float* out_dev,
-                             int32_t batch, void* stream);
+                             int32_t batch, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* Same interface (fp32 tensors in and out); Q, K, V and the softmax probabilities are rounded to bf16
  * and both products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation and fp32 softmax statistics
  * (the precision BASELINE.json names for the Swin / Pangu configs). */
 int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* desc, const float* qkv_dev,
                               const float* qkv_bias_dev, const float* table_dev, float* out_dev,
-                              int32_t batch, void* stream);
+                              int32_t batch, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * AFNO2D frequency-domain mixing (reference models/fourcastnet/fourcastnet.py:87-121): complex
