@@ -81,6 +81,11 @@ SIGNATURES = {
     "dlwp_fft2_plan_destroy": (c_int32, [c_void_p]),
     "dlwp_rfft2_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "dlwp_irfft2_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dlwp_afno_fft_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "dlwp_afno_fft_plan_create": (c_int32, [ctypes.POINTER(c_void_p), c_int32, c_int32, c_int32, c_void_p]),
+    "dlwp_afno_fft_plan_destroy": (c_int32, [c_void_p]),
+    "dlwp_afno_rfft2_kept_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "dlwp_afno_irfft2_kept_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "dlwp_conv3x3_cyl_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dlwp_conv3x3_hpx_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,

@@ -227,22 +227,63 @@ class _Fft2Plans:
 _fft2_plans = _Fft2Plans()
 
 
+class _AfnoFftPlans:
+    """twiddle tables of the hand-written kept-column FFTs per (device, H, W, kept columns)"""
+
+    def __init__(self):
+        self._plans = {}
+
+    def get(self, device, h: int, w: int, kc: int):
+        key = (str(device), h, w, kc)
+        if key not in self._plans:
+            lib = _lib.load()
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.dlwp_afno_fft_plan_create(ctypes.byref(handle), h, w, kc, _lib.stream_ptr()),
+                           "dlwp_afno_fft_plan_create")
+            self._plans[key] = handle
+        return self._plans[key]
+
+
+_afno_fft_plans = _AfnoFftPlans()
+
+
+def afno_kept_cols(h: int, w: int, hard_thresholding_fraction: float) -> int:
+    """columns of the half spectrum the filter keeps: fourcastnet.py:93-94 (`total_modes = H // 2 + 1` -- the
+    reference takes it from the FIRST spatial axis -- `kept_modes = int(total_modes * fraction)`, columns [:kept])"""
+    return max(0, min(int((h // 2 + 1) * hard_thresholding_fraction), w // 2 + 1))
+
+
 def afno2d_filter_cf(x_cf: torch.Tensor, w1, b1, w2, b2, num_blocks: int, sparsity_threshold: float,
-                     hard_thresholding_fraction: float) -> torch.Tensor:
+                     hard_thresholding_fraction: float, use_rocfft: bool = False) -> torch.Tensor:
     """irfft2(mix(rfft2(x_cf, norm="ortho")), norm="ortho") for CHANNELS-FIRST x_cf [B, C, H, W]
-    (fourcastnet.py:87-123 without the `+ bias` of :127): unnormalised hipFFT transforms, the two 1/sqrt(HW)
-    factors inside the mixing kernel, the spectrum mixed in place -- three launches + rocFFT's own kernels."""
+    (fourcastnet.py:87-123 without the `+ bias` of :127).  Three launches: the hand-written forward transform that
+    produces only the kept columns, the mixing kernel in place on that [B, C, H, kept] spectrum (it carries the two
+    1/sqrt(HW) factors of norm="ortho"), the hand-written inverse transform.  Grids that are not instantiated (and
+    use_rocfft=True, the cross-check) take the hipFFT path on the full half spectrum."""
     _lib.require_cuda_tensor(x_cf, "x_cf")
     x_cf = x_cf.contiguous()
     b, c, h, w = x_cf.shape
-    wf = w // 2 + 1
-    spec = torch.empty(b, c, h, wf, 2, device=x_cf.device, dtype=torch.float32)
-    y = torch.empty_like(x_cf)
     lib = _lib.load()
-    plan = _fft2_plans.get(x_cf.device, b * c, h, w)
     scale = 1.0 / float(h * w) ** 0.5
+    kc = afno_kept_cols(h, w, hard_thresholding_fraction)
+    y = torch.empty_like(x_cf)
     with torch.cuda.device(x_cf.device):
         st = _lib.stream_ptr()
+        if not use_rocfft and kc >= 1 and lib.dlwp_afno_fft_supported(h, w, kc):
+            plan = _afno_fft_plans.get(x_cf.device, h, w, kc)
+            spec = torch.empty(b, c, h, kc, 2, device=x_cf.device, dtype=torch.float32)
+            _lib.check(lib.dlwp_afno_rfft2_kept_f32(plan, x_cf.data_ptr(), spec.data_ptr(), b * c, st), "dlwp_afno_rfft2_kept_f32")
+            _lib.check(lib.dlwp_afno2d_mix_scaled_f32(spec.data_ptr(), spec.data_ptr(), w1.contiguous().data_ptr(),
+                                                      b1.contiguous().data_ptr(), w2.contiguous().data_ptr(),
+                                                      b2.contiguous().data_ptr(), b, h, kc, c, num_blocks,
+                                                      float(sparsity_threshold), float(hard_thresholding_fraction),
+                                                      scale, scale, st), "dlwp_afno2d_mix_scaled_f32")
+            _lib.check(lib.dlwp_afno_irfft2_kept_f32(plan, spec.data_ptr(), y.data_ptr(), b * c, st), "dlwp_afno_irfft2_kept_f32")
+            return y
+        wf = w // 2 + 1
+        spec = torch.empty(b, c, h, wf, 2, device=x_cf.device, dtype=torch.float32)
+        plan = _fft2_plans.get(x_cf.device, b * c, h, w)
         _lib.check(lib.dlwp_rfft2_f32(plan, x_cf.data_ptr(), spec.data_ptr(), st), "dlwp_rfft2_f32")
         _lib.check(lib.dlwp_afno2d_mix_scaled_f32(spec.data_ptr(), spec.data_ptr(), w1.contiguous().data_ptr(),
                                                   b1.contiguous().data_ptr(), w2.contiguous().data_ptr(),

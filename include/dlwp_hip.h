@@ -267,6 +267,22 @@ int32_t dlwp_fft2_plan_destroy(dlwp_fft2_plan* plan);
 int32_t dlwp_rfft2_f32(const dlwp_fft2_plan* plan, const float* x_dev, float* xf_dev, void* stream);
 int32_t dlwp_irfft2_f32(const dlwp_fft2_plan* plan, float* yf_dev, float* y_dev, void* stream);
 
+/* Hand-written 2-D real FFTs restricted to the columns the AFNO filter keeps (fourcastnet.py:85, :93-94, :124;
+ * csrc/afno_fft.hip): one workgroup per [H][W] plane, rows as packed-real FFTs, columns on the LDS-resident image,
+ * every complex FFT as two register passes (radix 4 / 8 / 16).  Unnormalised, like the hipFFT entry points above.
+ *   dlwp_afno_rfft2_kept_f32:  x_dev [planes][H][W] -> spec_dev [planes][H][kept_cols][2]
+ *   dlwp_afno_irfft2_kept_f32: spec_dev [planes][H][kept_cols][2] (columns >= kept_cols are zero; the imaginary part
+ *                              of column 0 is ignored, c2r semantics) -> y_dev [planes][H][W]; spec_dev is preserved.
+ * kept_cols = min(int((H/2+1) * hard_thresholding_fraction), W/2+1).  Instantiated grids: dlwp_afno_fft_supported. */
+typedef struct dlwp_afno_fft_plan dlwp_afno_fft_plan;
+int32_t dlwp_afno_fft_supported(int32_t height, int32_t width, int32_t kept_cols);
+int32_t dlwp_afno_fft_plan_create(dlwp_afno_fft_plan** out, int32_t height, int32_t width, int32_t kept_cols, void* stream);
+int32_t dlwp_afno_fft_plan_destroy(dlwp_afno_fft_plan* plan);
+int32_t dlwp_afno_rfft2_kept_f32(const dlwp_afno_fft_plan* plan, const float* x_dev, float* spec_dev, int32_t planes,
+                                 void* stream);
+int32_t dlwp_afno_irfft2_kept_f32(const dlwp_afno_fft_plan* plan, const float* spec_dev, float* y_dev, int32_t planes,
+                                  void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * CylinderPad(1) + Conv2d(3x3, padding 0) + bias + activation, input optionally given as two
  * channel segments (folds the preceding torch.cat).  Reference: utils/utils.py:11-26;
