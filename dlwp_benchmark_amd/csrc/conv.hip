@@ -35,6 +35,8 @@ struct Params {
   const float* bias;         // [Cout] or null
   float* y;                  // [B][Cout][H][W]
   int B, H, W, Cout, act;
+  int pre_act;               // activation applied to the INPUT while it is staged (pre-activation residual blocks, unet.py:886)
+  const float* resid;        // [B][Cout][H][W] or null: added after bias, before `act` (block shortcut, unet.py:901)
   // HEALPix topology (null = cylinder): [12][(H+2)*(W+2)] entries (a, b) for the halo ring of every face;
   // a, b = face*H*W + pixel inside the same sample, b < 0 -> single source, else the mean of both
   // (the synthesised corners of the equatorial faces, reference utils/healpix.py:316-368).
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(TH * TW) void conv3x3_cyl_kernel(const Params p) {
         const int ih = h0 + r - 1;
         int iw = w0 + cc - 1;
         float v = 0.f;
+        bool corner_done = false;
         if (p.hpx) {
           if (c < cin && ih >= -1 && ih <= p.H && iw >= -1 && iw <= p.W) {
             const bool seg0 = c < p.c0;
@@ -86,8 +89,12 @@ __global__ __launch_bounds__(TH * TW) void conv3x3_cyl_kernel(const Params p) {
               const int fa = e.x / (int)HW;
               v = base[((long long)(s0 + fa) * cs + cl) * HW + (e.x - fa * (int)HW)];
               if (e.y >= 0) {
+                // a synthesised corner is the mean of two cells of the ACTIVATED tensor (the reference pads after the
+                // activation, unet.py:886-887): activate each source, then average; flag the value as done
                 const int fb = e.y / (int)HW;
-                v = 0.5f * v + 0.5f * base[((long long)(s0 + fb) * cs + cl) * HW + (e.y - fb * (int)HW)];
+                const float v2 = base[((long long)(s0 + fb) * cs + cl) * HW + (e.y - fb * (int)HW)];
+                if (p.pre_act) { v = 0.5f * apply_act(v, p.pre_act) + 0.5f * apply_act(v2, p.pre_act); corner_done = true; }
+                else v = 0.5f * v + 0.5f * v2;
               }
             }
           }
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(TH * TW) void conv3x3_cyl_kernel(const Params p) {
                                       : p.x1 + ((long long)b * p.c1 + (c - p.c0)) * HW;
           v = src[(long long)ih * p.W + iw];
         }
-        (&s_in[0][0][0])[i] = v;
+        (&s_in[0][0][0])[i] = (p.pre_act && !corner_done) ? apply_act(v, p.pre_act) : v;   // padding zeros stay zero (act(0) = 0)
       }
       for (int i = tid; i < CO_CHUNK * CI_CHUNK * 9; i += NT) {
         const int k = i / (CI_CHUNK * 9), rem = i % (CI_CHUNK * 9);
@@ -125,7 +132,9 @@ __global__ __launch_bounds__(TH * TW) void conv3x3_cyl_kernel(const Params p) {
         const int co = co0 + k;
         if (co < p.Cout) {
           float v = acc[k] + (p.bias ? p.bias[co] : 0.f);
-          p.y[((long long)b * p.Cout + co) * HW + (long long)oh * p.W + ow] = apply_act(v, p.act);
+          const long long o = ((long long)b * p.Cout + co) * HW + (long long)oh * p.W + ow;
+          if (p.resid) v += p.resid[o];
+          p.y[o] = apply_act(v, p.act);
         }
       }
     }
@@ -200,6 +209,29 @@ static void launch_conv3x3(const conv::Params& p, hipStream_t s) {
   else launch_conv3x3_co<4>(p, s);
 }
 
+extern "C" int32_t dlwp_conv3x3_ex_f32(const float* x0, int32_t c0, const float* x1, int32_t c1, const float* weight,
+                                       const float* bias, const float* resid, float* y, int32_t batch, int32_t H, int32_t W,
+                                       int32_t cout, int32_t pre_act, int32_t act, const int32_t* ring_table, void* stream) {
+  DLWP_REQUIRE(x0 && weight && y, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0 && H > 0 && W > 0 && c0 > 0 && cout > 0 && c1 >= 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
+  DLWP_REQUIRE(c1 == 0 || x1, DLWP_ERR_INVALID_ARGUMENT, "second segment pointer missing");
+  DLWP_REQUIRE(act >= 0 && act <= 4 && pre_act >= 0 && pre_act <= 4, DLWP_ERR_INVALID_ARGUMENT, "unknown activation");
+  DLWP_REQUIRE(batch <= 65535, DLWP_ERR_UNSUPPORTED, "batch %d exceeds the grid's y dimension", batch);
+  if (ring_table) {
+    DLWP_REQUIRE(batch % 12 == 0, DLWP_ERR_INVALID_ARGUMENT, "n_faces=%d is not a multiple of 12", batch);
+    DLWP_REQUIRE((long long)12 * H * W < (1ll << 31), DLWP_ERR_INVALID_ARGUMENT, "face too large for the 32-bit table");
+  } else {
+    DLWP_REQUIRE(W > 1, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
+  }
+  conv::Params p;
+  p.x0 = x0; p.c0 = c0; p.x1 = x1; p.c1 = c1; p.w = weight; p.bias = bias; p.y = y;
+  p.B = batch; p.H = H; p.W = W; p.Cout = cout; p.act = act; p.pre_act = pre_act; p.resid = resid;
+  p.hpx = reinterpret_cast<const int2*>(ring_table);
+  launch_conv3x3(p, reinterpret_cast<hipStream_t>(stream));
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
 extern "C" int32_t dlwp_conv3x3_cyl_f32(const float* x0, int32_t c0, const float* x1, int32_t c1, const float* weight,
                                         const float* bias, float* y, int32_t batch, int32_t H, int32_t W, int32_t cout,
                                         int32_t act, void* stream) {
@@ -209,7 +241,7 @@ extern "C" int32_t dlwp_conv3x3_cyl_f32(const float* x0, int32_t c0, const float
   DLWP_REQUIRE(act >= 0 && act <= 4, DLWP_ERR_INVALID_ARGUMENT, "unknown activation %d", act);
   conv::Params p;
   p.x0 = x0; p.c0 = c0; p.x1 = x1; p.c1 = c1; p.w = weight; p.bias = bias; p.y = y;
-  p.B = batch; p.H = H; p.W = W; p.Cout = cout; p.act = act; p.hpx = nullptr;
+  p.B = batch; p.H = H; p.W = W; p.Cout = cout; p.act = act; p.hpx = nullptr; p.pre_act = 0; p.resid = nullptr;
   DLWP_REQUIRE(batch <= 65535, DLWP_ERR_UNSUPPORTED, "batch %d exceeds the grid's y dimension", batch);
   launch_conv3x3(p, reinterpret_cast<hipStream_t>(stream));
   DLWP_HIP_CHECK(hipGetLastError());
@@ -228,6 +260,7 @@ extern "C" int32_t dlwp_conv3x3_hpx_f32(const float* x0, int32_t c0, const float
   conv::Params p;
   p.x0 = x0; p.c0 = c0; p.x1 = x1; p.c1 = c1; p.w = weight; p.bias = bias; p.y = y;
   p.B = n_faces; p.H = H; p.W = W; p.Cout = cout; p.act = act; p.hpx = reinterpret_cast<const int2*>(ring_table);
+  p.pre_act = 0; p.resid = nullptr;
   DLWP_REQUIRE(n_faces <= 65535, DLWP_ERR_UNSUPPORTED, "n_faces %d exceeds the grid's y dimension", n_faces);
   launch_conv3x3(p, reinterpret_cast<hipStream_t>(stream));
   DLWP_HIP_CHECK(hipGetLastError());

@@ -88,6 +88,15 @@ SIGNATURES = {
     "dlwp_afno_irfft2_kept_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "dlwp_conv3x3_cyl_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "dlwp_conv3x3_ex_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                      c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "dlwp_groupnorm_act_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
+                                         c_int32, c_void_p]),
+    "dlwp_conv2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "dlwp_conv_transpose2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                            c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "dlwp_avgpool2x2_f32": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_void_p]),
     "dlwp_conv3x3_hpx_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "dlwp_healpix_pad_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -94,7 +94,6 @@ class ResidualBlock(nn.Module):
         # unet.py:867-872: HEALPixPadding on the HEALPix mesh, CylinderPad otherwise; either way the padding happens
         # inside the fused convolution kernel
         self.cylinder_pad = HEALPixPadding(padding=1) if mesh == "healpix" else CylinderPad(1)
-        self._conv = ops.conv3x3_hpx if mesh == "healpix" else ops.conv3x3_cyl
         self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=0)
         self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=0)
         with torch.no_grad():   # zero_module (unet.py:762-766)
@@ -105,14 +104,24 @@ class ResidualBlock(nn.Module):
         self.norm2 = nn.GroupNorm(n_groups, out_channels) if norm else nn.Identity()
 
     def forward(self, x):
+        """unet.py:884-901 in two or four launches: without norms `act(x)` rides in conv1's input staging and the
+        second activation in its epilogue; with GroupNorm each `act(norm(.))` is one dlwp_groupnorm_act_f32 launch.
+        The shortcut (identity or 1x1 convolution) is added in conv2's epilogue."""
         gelu = ops.act_code(self.activation)
-        h = F.gelu(self.norm1(x))
-        if isinstance(self.norm2, nn.Identity):
-            h = self._conv(h, self.conv1.weight, self.conv1.bias, gelu)
+        hpx = self.mesh == "healpix"
+        x = x.contiguous()
+        short = x if isinstance(self.shortcut, nn.Identity) else ops.conv2d(x, self.shortcut.weight, self.shortcut.bias)
+        n1, n2 = self.norm1, self.norm2
+        if isinstance(n1, nn.Identity):
+            h, pre = x, gelu
         else:
-            h = F.gelu(self.norm2(self._conv(h, self.conv1.weight, self.conv1.bias, 0)))
-        h = self._conv(h, self.conv2.weight, self.conv2.bias, 0)
-        return h + self.shortcut(x)
+            h, pre = ops.groupnorm_act(x, n1.weight, n1.bias, n1.num_groups, n1.eps, gelu), 0
+        if isinstance(n2, nn.Identity):
+            h = ops.conv3x3(h, self.conv1.weight, self.conv1.bias, act=gelu, pre_act=pre, hpx=hpx)
+        else:
+            h = ops.conv3x3(h, self.conv1.weight, self.conv1.bias, act=0, pre_act=pre, hpx=hpx)
+            h = ops.groupnorm_act(h, n2.weight, n2.bias, n2.num_groups, n2.eps, gelu)
+        return ops.conv3x3(h, self.conv2.weight, self.conv2.bias, act=0, resid=short, hpx=hpx)
 
 
 class MiddleBlock(nn.Module):
@@ -175,7 +184,7 @@ def _run_stack(seq: nn.Sequential, x, skip=None):
             if skip is not None:
                 x = torch.cat([skip, x], dim=1)
                 skip = None
-            x = m(x)
+            x = ops.small_module(m, x)      # AvgPool2d(2) / ConvTranspose2d / plain Conv2d: HIP kernels, no torch op
             i += 1
     return x
 
@@ -232,7 +241,7 @@ class _UNetDecoder(nn.Module):
     def forward(self, x, skips):
         for l_idx, layer in enumerate(self.layers):
             x = _run_stack(layer, x, skip=skips[l_idx] if l_idx > 0 else None)
-        return self.output_layer(x)
+        return ops.small_module(self.output_layer, x)
 
 
 class UNet(HipBackbone):
@@ -334,7 +343,7 @@ class _ModernUNetEncoder(nn.Module):
 
     def forward(self, x):
         for layer in self.layers:
-            x = layer[1](layer[0](x))
+            x = layer[1](ops.small_module(layer[0], x))    # strided 3x3 / 1x1 convolution, then the residual block
         return x
 
 
@@ -368,8 +377,10 @@ class _ModernUNetDecoder(nn.Module):
     def forward(self, x):
         for layer in self.layers:
             for sub in layer:
-                x = sub(x)
-        return self.output_layer(self.activation(self.final_norm(x)))
+                x = ops.small_module(sub, x) if isinstance(sub, nn.ConvTranspose2d) else sub(x)
+        fn = self.final_norm
+        x = ops.groupnorm_act(x, fn.weight, fn.bias, fn.num_groups, fn.eps, ops.act_code(self.activation))
+        return ops.small_module(self.output_layer, x)
 
 
 class MUNetHPX(UNetHPX):

@@ -155,6 +155,136 @@ def conv3x3_hpx(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return y
 
 
+def conv3x3(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
+            x1: Optional[torch.Tensor] = None, pre_act: int = 0, resid: Optional[torch.Tensor] = None,
+            hpx: bool = False) -> torch.Tensor:
+    """pad(1) + Conv2d(3x3) on cat([x0, x1], 1) with the input activation `pre_act` applied while staging and
+    `resid` added before `act`; padding rule: CylinderPad, or HEALPixPadding when hpx (x [(B*12), C, H, W])."""
+    for t, n in ((x0, "x0"), (x1, "x1"), (weight, "weight"), (resid, "resid")):
+        _lib.require_cuda_tensor(t, n)
+    x0 = x0.contiguous()
+    x1 = x1.contiguous() if x1 is not None else None
+    weight = weight.contiguous()
+    n, c0, h, w = x0.shape
+    c1 = x1.shape[1] if x1 is not None else 0
+    cout = weight.shape[0]
+    if tuple(weight.shape[1:]) != (c0 + c1, 3, 3):
+        raise _lib.DlwpError(f"weight {tuple(weight.shape)} does not match {c0}+{c1} input channels, 3x3")
+    if resid is not None and (tuple(resid.shape) != (n, cout, h, w) or not resid.is_contiguous()):
+        raise _lib.DlwpError("conv3x3: resid must be contiguous and shaped like the output")
+    table = None
+    if hpx:
+        from . import healpix as _hpx
+
+        if n % 12:
+            raise _lib.DlwpError(f"leading dimension {n} is not (batch * 12 faces)")
+        table = _hpx.device_table(h, w, 1, x0.device)
+    y = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x0.device):
+        _lib.check(lib.dlwp_conv3x3_ex_f32(x0.data_ptr(), c0, x1.data_ptr() if x1 is not None else None, c1, weight.data_ptr(),
+                                           bias.contiguous().data_ptr() if bias is not None else None,
+                                           resid.data_ptr() if resid is not None else None, y.data_ptr(), n, h, w, cout,
+                                           int(pre_act), int(act), table.data_ptr() if table is not None else None,
+                                           _lib.stream_ptr()), "dlwp_conv3x3_ex_f32")
+    return y
+
+
+def groupnorm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], groups: int,
+                  eps: float = 1e-5, act: int = 0) -> torch.Tensor:
+    """act(GroupNorm(groups)(x)) for x [N, C, ...] (reference unet.py:739 + :761, :887-888), one launch."""
+    _lib.require_cuda_tensor(x, "x")
+    x = x.contiguous()
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_groupnorm_act_f32(x.data_ptr(), weight.contiguous().data_ptr() if weight is not None else None,
+                                              bias.contiguous().data_ptr() if bias is not None else None, y.data_ptr(), n, c,
+                                              hw, int(groups), float(eps), int(act), _lib.stream_ptr()),
+                   "dlwp_groupnorm_act_f32")
+    return y
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 0,
+           pre_act: int = 0, act: int = 0, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """zero-padded Conv2d (square kernel / stride / padding): the strided and 1x1 convolutions of unet.py:583-584, :879, :450."""
+    for t, n in ((x, "x"), (weight, "weight"), (resid, "resid")):
+        _lib.require_cuda_tensor(t, n)
+    x, weight = x.contiguous(), weight.contiguous()
+    n, cin, h, w = x.shape
+    cout, cin_w, k, k2 = weight.shape
+    if cin_w != cin or k != k2:
+        raise _lib.DlwpError(f"conv2d: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
+    oh, ow = (h + 2 * padding - k) // stride + 1, (w + 2 * padding - k) // stride + 1
+    if resid is not None and (tuple(resid.shape) != (n, cout, oh, ow) or not resid.is_contiguous()):
+        raise _lib.DlwpError("conv2d: resid must be contiguous and shaped like the output")
+    y = torch.empty(n, cout, oh, ow, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_conv2d_f32(x.data_ptr(), weight.data_ptr(), bias.contiguous().data_ptr() if bias is not None else None,
+                                       resid.data_ptr() if resid is not None else None, y.data_ptr(), n, cin, h, w, cout, k,
+                                       int(stride), int(padding), int(pre_act), int(act), _lib.stream_ptr()), "dlwp_conv2d_f32")
+    return y
+
+
+def conv_transpose2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, padding: int = 0,
+                     act: int = 0) -> torch.Tensor:
+    """ConvTranspose2d (weight [cin, cout, k, k]; unet.py:523 2x2 s2, :719 4x4 s2 p1)."""
+    _lib.require_cuda_tensor(x, "x")
+    _lib.require_cuda_tensor(weight, "weight")
+    x, weight = x.contiguous(), weight.contiguous()
+    n, cin, h, w = x.shape
+    cin_w, cout, k, k2 = weight.shape
+    if cin_w != cin or k != k2:
+        raise _lib.DlwpError(f"conv_transpose2d: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
+    oh, ow = (h - 1) * stride - 2 * padding + k, (w - 1) * stride - 2 * padding + k
+    y = torch.empty(n, cout, oh, ow, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_conv_transpose2d_f32(x.data_ptr(), weight.data_ptr(),
+                                                 bias.contiguous().data_ptr() if bias is not None else None, y.data_ptr(), n,
+                                                 cin, h, w, cout, k, int(stride), int(padding), int(act), _lib.stream_ptr()),
+                   "dlwp_conv_transpose2d_f32")
+    return y
+
+
+def avgpool2x2(x: torch.Tensor) -> torch.Tensor:
+    """AvgPool2d(kernel_size=2, stride=2) (unet.py:450)."""
+    _lib.require_cuda_tensor(x, "x")
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_avgpool2x2_f32(x.data_ptr(), y.data_ptr(), n * c, h, w, _lib.stream_ptr()), "dlwp_avgpool2x2_f32")
+    return y
+
+
+def small_module(m: torch.nn.Module, x: torch.Tensor, act: int = 0) -> torch.Tensor:
+    """Runs one of the U-Net family's non-3x3 layers through its HIP kernel: AvgPool2d(2), ConvTranspose2d, Conv2d
+    (zero padding, square); raises for anything else so that nothing silently falls back to a torch op."""
+    nn = torch.nn
+    if isinstance(m, nn.AvgPool2d):
+        k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+        s_ = m.stride if isinstance(m.stride, int) else m.stride[0]
+        if k != 2 or s_ != 2 or m.padding not in (0, (0, 0)):
+            raise _lib.DlwpError("only AvgPool2d(2, 2) has a kernel")
+        return avgpool2x2(x)
+    if isinstance(m, nn.ConvTranspose2d):
+        if m.kernel_size[0] != m.kernel_size[1] or m.stride[0] != m.stride[1] or m.padding[0] != m.padding[1] or \
+                m.output_padding != (0, 0) or m.dilation != (1, 1) or m.groups != 1:
+            raise _lib.DlwpError("ConvTranspose2d: only square kernel / stride / padding without output_padding, dilation, groups")
+        return conv_transpose2d(x, m.weight, m.bias, m.stride[0], m.padding[0], act)
+    if isinstance(m, nn.Conv2d):
+        if m.kernel_size[0] != m.kernel_size[1] or m.stride[0] != m.stride[1] or m.padding[0] != m.padding[1] or \
+                m.dilation != (1, 1) or m.groups != 1 or m.padding_mode != "zeros":
+            raise _lib.DlwpError("Conv2d: only square kernel / stride / zero padding without dilation or groups")
+        return conv2d(x, m.weight, m.bias, m.stride[0], m.padding[0], act=act)
+    raise _lib.DlwpError(f"no HIP kernel for {type(m).__name__}")
+
+
 def healpix_pad(x: torch.Tensor, padding: int) -> torch.Tensor:
     """HEALPixPadding(padding) (reference utils/healpix.py:165-368): [(B*12), C, H, W] -> [(B*12), C, H+2p, W+2p]."""
     from . import healpix as _hpx

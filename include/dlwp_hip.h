@@ -294,6 +294,32 @@ int32_t dlwp_conv3x3_cyl_f32(const float* x0_dev, int32_t c0, const float* x1_de
                              const float* weight_dev, const float* bias_dev, float* y_dev, int32_t batch,
                              int32_t height, int32_t width, int32_t cout, int32_t act, void* stream);
 
+/* The same convolution with two more fusions and either padding rule: pre_act is applied to the input while it is staged
+ * (pre-activation residual blocks, unet.py:886 `h = act(norm1(x))` when norm1 is the identity), resid_dev [B, cout, H, W]
+ * or NULL is added after the bias and before `act` (the block's shortcut, unet.py:901).  ring_table NULL: CylinderPad;
+ * otherwise the HEALPix halo table of dlwp_conv3x3_hpx_f32 (batch = 12 * samples faces). */
+int32_t dlwp_conv3x3_ex_f32(const float* x0_dev, int32_t c0, const float* x1_dev, int32_t c1, const float* weight_dev,
+                            const float* bias_dev, const float* resid_dev, float* y_dev, int32_t batch, int32_t height,
+                            int32_t width, int32_t cout, int32_t pre_act, int32_t act, const int32_t* ring_table, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The remaining U-Net / ModernUNet operators (csrc/conv2.hip), NCHW fp32, activations as above.
+ *   dlwp_groupnorm_act_f32     y = act(GroupNorm(groups)(x)): unet.py:739 (+ GELU :761), :887-888; gamma / beta [C] or NULL
+ *   dlwp_conv2d_f32            zero-padded Conv2d k x k, stride s: unet.py:583 (3x3 s2 p1), :584 / :879 / :450 (1x1);
+ *                              optional pre_act on the input and resid_dev [N, cout, OH, OW] before `act`
+ *   dlwp_conv_transpose2d_f32  ConvTranspose2d k x k, stride s, padding p (weight [cin, cout, k, k]): unet.py:719, :523
+ *   dlwp_avgpool2x2_f32        AvgPool2d(2): unet.py:450
+ * ------------------------------------------------------------------------------------------ */
+int32_t dlwp_groupnorm_act_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, int32_t batch,
+                               int32_t channels, int32_t hw, int32_t groups, float eps, int32_t act, void* stream);
+int32_t dlwp_conv2d_f32(const float* x_dev, const float* weight_dev, const float* bias_dev, const float* resid_dev, float* y_dev,
+                        int32_t batch, int32_t cin, int32_t height, int32_t width, int32_t cout, int32_t k, int32_t stride,
+                        int32_t pad, int32_t pre_act, int32_t act, void* stream);
+int32_t dlwp_conv_transpose2d_f32(const float* x_dev, const float* weight_dev, const float* bias_dev, float* y_dev, int32_t batch,
+                                  int32_t cin, int32_t height, int32_t width, int32_t cout, int32_t k, int32_t stride,
+                                  int32_t pad, int32_t act, void* stream);
+int32_t dlwp_avgpool2x2_f32(const float* x_dev, float* y_dev, int64_t planes, int32_t height, int32_t width, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * HEALPix mesh.  Faces are folded into the batch, [(B*12), C, H, W], face index fastest
  * (reference models/unet/unet.py:413-426 `b c f h w -> (b f) c h w`).  The neighbour topology of
