@@ -122,6 +122,16 @@ MODEL_CASES = {
 }
 
 
+# Full-width configs at their CONFIGURED horizons (C3: 12 steps = 72 h at 6 h; C4: 20 steps; C5: 5 steps), one initial
+# condition.  Only every `stride`-th pixel of the trajectory is committed (the two-step *_full fixtures above cover
+# every pixel): tag -> (base case, frames, pixel stride)
+HORIZON_CASES = {
+    "swin_c3_full_h12": ("swin_c3_full", 13, 1),
+    "afno_c4_full_h20": ("afno_c4_full", 21, 4),
+    "pangu_c5_full_h5": ("pangu_c5_full", 6, 4),
+}
+
+
 def model_inputs(tag, cfg, batch, frames):
     """Seeded inputs of the dataset tuple layout; identical on every machine (numpy Generator)."""
     from dlwp_benchmark_amd.synthetic import navier_stokes, weatherbench
@@ -191,6 +201,19 @@ def gen_models(ref, only=None):
         full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]
         _save(f"model_{tag}", y=y.numpy().astype(np.float32), sha=np.array(sha),
               param_spec=np.array(json.dumps(spec)), state_spec=np.array(json.dumps(full)))
+
+
+def gen_horizons(ref, only=None):
+    for tag, (base, frames, stride) in HORIZON_CASES.items():
+        if only and tag not in only:
+            continue
+        family, cfg, (batch, _), gain = MODEL_CASES[base]
+        m = build_reference(ref, family, cfg)
+        sha = W.fill_state_dict(m, gain=gain)
+        constants, prescribed, prognostic = model_inputs(base, cfg, batch, frames)
+        y = reference_rollout(m, family, cfg, constants, prescribed, prognostic)
+        _save(f"model_{tag}", y=y.numpy().astype(np.float32)[..., ::stride, ::stride], sha=np.array(sha),
+              stride=np.array(stride), frames=np.array(frames))
 
 
 # ------------------------------------------------------------------------------------------
@@ -304,8 +327,11 @@ def main():
         gen_spectral(ref)
     if not only or "hpx" in only:
         gen_hpx(ref)
-    if not only or (only - {"spectral", "hpx"}):
-        gen_models(ref, (only - {"spectral", "hpx"}) if only else None)
+    rest = only - {"spectral", "hpx"} - set(HORIZON_CASES) - {"horizons"}
+    if not only or rest:
+        gen_models(ref, rest if only else None)
+    if not only or "horizons" in only or (only & set(HORIZON_CASES)):
+        gen_horizons(ref, (only & set(HORIZON_CASES)) or None)
 
 
 if __name__ == "__main__":

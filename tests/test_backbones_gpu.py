@@ -392,3 +392,43 @@ def test_modernunet_latlon_runs_through_hip():
     assert torch.equal(out, model(constants=c, prescribed=p, prognostic=g))
     one = model(constants=c[1:2], prescribed=p[1:2], prognostic=g[1:2])
     assert rel_l2(one, out[1:2]) <= 1e-6
+
+
+def _horizon_cases():
+    from oracle.make_golden import HORIZON_CASES
+
+    return list(HORIZON_CASES)
+
+
+@pytest.mark.parametrize("tag", _horizon_cases())
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_width_rollout_at_configured_horizon(tag, precision):
+    """BASELINE configs C3 / C4 / C5 at FULL width over their CONFIGURED horizons (12 / 20 / 5 steps, one initial
+    condition) against the trajectory of the real reference classes: fp32 path <= 1e-5 per step; bf16 window attention
+    (the precision BASELINE names for C3 / C5) within its stated 5e-3 bound at every lead time."""
+    import dlwp_benchmark_amd.models as M
+    from dlwp_benchmark_amd.weights import fill_state_dict
+    from oracle.make_golden import HORIZON_CASES, MODEL_CASES, model_inputs
+
+    base, frames, stride = HORIZON_CASES[tag]
+    family, cfg, (batch, _), gain = MODEL_CASES[base]
+    if precision == "bf16" and family == "afno":
+        pytest.skip("FourCastNet has no attention")
+    name, _ = _product_class(family)
+    g = load_golden(f"model_{tag}")
+    model = getattr(M, name)(**cfg)
+    sha = fill_state_dict(model, gain=gain)
+    assert sha == str(g["sha"]), "filler drifted: regenerate fixtures"
+    model = model.to("cuda:0").eval()
+    if precision == "bf16":
+        model.set_attention_precision("bf16")
+    constants, prescribed, prognostic = model_inputs(base, cfg, batch, frames)
+    dev = lambda t: t.to("cuda:0") if t is not None else None
+    got = model(constants=dev(constants), prescribed=dev(prescribed), prognostic=dev(prognostic))
+    torch.cuda.synchronize()
+    want = torch.from_numpy(g["y"])
+    got = got[..., ::stride, ::stride]
+    assert got.shape == want.shape
+    errs = per_step_rel_l2(got, want)
+    print(tag, precision, "per-step rel L2:", ["%.2e" % e for e in errs])
+    assert max(errs) <= (5e-3 if precision == "bf16" else TOL), errs

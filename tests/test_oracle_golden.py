@@ -146,3 +146,23 @@ def test_convlstm_hpx_restatement_matches_reference(tag):
     ref = torch.from_numpy(g["y"])
     assert y.shape == ref.shape
     assert max(rel_l2(y[:, t], ref[:, t]) for t in range(ref.shape[1])) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["swin_c3_full_h12", "afno_c4_full_h20"])
+def test_backbone_restatement_matches_reference_at_configured_horizon(tag):
+    """C3 (12 steps) and C4 (20 steps) at full width: the restatement against the real classes' trajectory (C5's five
+    steps take ~30 s of CPU and are covered on the GPU side only)."""
+    from oracle.make_golden import HORIZON_CASES
+
+    base, frames, stride = HORIZON_CASES[tag]
+    family, cfg, (batch, _), gain = MODEL_CASES[base]
+    g = load_golden(f"model_{tag}")
+    spec = json.loads(str(load_golden(f"model_{base}")["param_spec"]))
+    sd, sha = fill_by_spec(spec, gain=gain)
+    assert sha == str(g["sha"]), "filler drifted: regenerate fixtures"
+    constants, prescribed, prognostic = model_inputs(base, cfg, batch, frames)
+    with torch.no_grad():
+        y = ROLLOUTS[family](sd, cfg, constants, prescribed, prognostic)[..., ::stride, ::stride]
+    want = torch.from_numpy(g["y"])
+    assert y.shape == want.shape
+    assert max(rel_l2(y[:, t], want[:, t]) for t in range(want.shape[1])) < 1e-6
