@@ -48,13 +48,19 @@ class HipBackbone(torch.nn.Module):
         _lib.require_cuda_tensor(prognostic, "prognostic")
         _lib.require_cuda_tensor(constants, "constants")
         _lib.require_cuda_tensor(prescribed, "prescribed")
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError(
-                "the MI355X path implements the inference rollout (evaluate.py); training through the "
-                "HIP kernels (backward passes) is not implemented yet -- call .eval() / torch.no_grad()")
         c = constants.contiguous() if constants is not None else None
         p = prescribed.contiguous() if prescribed is not None else None
         return c, p, prognostic.contiguous()
+
+    def _grad_mode(self) -> bool:
+        """train.py:263-271: `.train()` + autograd recording -> the differentiable rollout (dlwp_benchmark_amd/training.py:
+        the hot kernels run their HIP forward inside autograd Functions, the pointwise layers are torch operators)."""
+        return self.training and torch.is_grad_enabled()
+
+    def _forward_train(self, constants, prescribed, prognostic):
+        from ..rollout import rollout_train
+
+        return rollout_train(self.one_step, self.context_size, constants, prescribed, prognostic)
 
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:

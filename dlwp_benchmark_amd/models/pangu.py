@@ -117,7 +117,7 @@ class _EarthSpecificBlock(nn.Module):
             mask_b1=(ppl - wpl, plat - wlat, plon + slon - wlon) if self.roll else (ops.BIG,) * 3,
             mask_b2=(ppl - spl, plat - slat, plon) if self.roll else (ops.BIG,) * 3,
             bias_mode=1, heads=self.num_heads, head_dim=self.dim // self.num_heads, scale=self.attn.scale)
-        if not x.is_contiguous():
+        if not x.is_contiguous() or (self.training and torch.is_grad_enabled()):   # (training: no in-place residual form)
             if pend is not None:
                 x = x + pend
             qkv = self.attn.qkv(self.norm1(x))
@@ -277,6 +277,8 @@ class PanguWeather(HipBackbone):
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
         constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
+        if self._grad_mode():
+            return self._forward_train(constants, prescribed, prognostic)
         with torch.no_grad():
             b, t, cg, h, w = prognostic.shape
             if t <= self.context_size:

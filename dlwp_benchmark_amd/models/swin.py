@@ -79,7 +79,8 @@ class _Block(nn.Module):
             # region ids from the slices of swin_transformer.py:385-390 (shift = window // 2 there)
             mask_b1=(ops.BIG, h - wh, w - ww), mask_b2=(ops.BIG, h - wh // 2, w - ww // 2),
             bias_mode=0, heads=self.num_heads, head_dim=self.dim // self.num_heads, scale=self.attn.scale)
-        deferred = isinstance(self.norm1, ops.HipLayerNorm) and isinstance(self.norm2, ops.HipLayerNorm) and x.is_contiguous()
+        deferred = isinstance(self.norm1, ops.HipLayerNorm) and isinstance(self.norm2, ops.HipLayerNorm) and x.is_contiguous() \
+            and not (self.training and torch.is_grad_enabled())     # the in-place residual form is inference only
         if not deferred:
             if pend is not None:
                 x = x + pend
@@ -230,6 +231,8 @@ class SwinTransformer(HipBackbone):
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
         constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
+        if self._grad_mode():
+            return self._forward_train(constants, prescribed, prognostic)
         with torch.no_grad():
             b, t, cg, h, w = prognostic.shape
             if t <= self.context_size:

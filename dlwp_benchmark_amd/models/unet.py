@@ -268,6 +268,8 @@ class UNet(HipBackbone):
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
         constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
+        if self._grad_mode():
+            return self._forward_train(constants, prescribed, prognostic)
         with torch.no_grad():
             b, t, cg, h, w = prognostic.shape
             if t <= self.context_size:
@@ -304,12 +306,17 @@ class UNetHPX(UNet):
                     raise _lib.DlwpError(f"{name}: expected [B, T, C, 12, H, W], got {tuple(t.shape)}")
         if prognostic is None:
             raise _lib.DlwpError("prognostic is required")
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training is a 'next' row (SURVEY.md 8f f4); call .eval() / no_grad()")
         ctx = self.context_size
         b, t_total, cg, f, h, w = prognostic.shape
         if t_total <= ctx:
             raise _lib.DlwpError(f"need more than context_size={ctx} frames, got {t_total}")
+        if self._grad_mode():
+            from ..rollout import rollout_train
+
+            fold = lambda t: t.permute(0, 3, 1, 2, 4, 5).reshape(b * f, t.shape[1], t.shape[2], h, w).float()
+            out = rollout_train(self.one_step, ctx, fold(constants) if constants is not None else None,
+                                fold(prescribed) if prescribed is not None else None, fold(prognostic))
+            return out.reshape(b, f, t_total - ctx, cg, h, w).permute(0, 2, 3, 1, 4, 5)
         with torch.no_grad():
             # face-folded working layout [(B F), T, C, H, W]: the generic rollout then runs unchanged
             fold5 = lambda t: t.permute(0, 3, 1, 2, 4, 5).reshape(b * f, t.shape[1], t.shape[2], h, w).float().contiguous()
@@ -486,18 +493,21 @@ class ConvLSTM(HipBackbone):
         self.context_size = int(context_size)
         in_size = constant_channels + prescribed_channels + prognostic_channels
         h0 = self.hidden_sizes[0]
-        if mesh == "healpix":   # convlstm.py:155-161, :186-193
-            hpx = lambda ci, co: HEALPixLayer(layer=nn.Conv2d, in_channels=ci, out_channels=co, kernel_size=3, padding=1)
+        # registration order encoder, clstm, decoder as in the reference (:148-193): state_dict() iterates in that order
+        hpx = lambda ci, co: HEALPixLayer(layer=nn.Conv2d, in_channels=ci, out_channels=co, kernel_size=3, padding=1)
+        if mesh == "healpix":   # convlstm.py:155-161
             self.encoder = nn.Sequential(hpx(in_size, h0), nn.Tanh(), hpx(h0, h0), nn.Tanh(), hpx(h0, h0))
-            self.decoder = hpx(self.hidden_sizes[-1], prognostic_channels)
         else:
             self.encoder = nn.Sequential(
                 CylinderPad(1), nn.Conv2d(in_size, h0, kernel_size=3, padding=0), nn.Tanh(),
                 CylinderPad(1), nn.Conv2d(h0, h0, kernel_size=3, padding=0), nn.Tanh(),
                 CylinderPad(1), nn.Conv2d(h0, h0, kernel_size=3, padding=0))
+        self.clstm = nn.Sequential(*[_ConvLSTMCell(hs, hs, bias, mesh) for hs in self.hidden_sizes])
+        if mesh == "healpix":   # convlstm.py:186-193
+            self.decoder = hpx(self.hidden_sizes[-1], prognostic_channels)
+        else:
             self.decoder = nn.Sequential(CylinderPad(1), nn.Conv2d(self.hidden_sizes[-1], prognostic_channels,
                                                                    kernel_size=3, padding=0))
-        self.clstm = nn.Sequential(*[_ConvLSTMCell(hs, hs, bias, mesh) for hs in self.hidden_sizes])
 
     def _decode(self, x):
         return self.decoder(x) if isinstance(self.decoder, HEALPixLayer) else _run_stack(self.decoder, x)
@@ -513,7 +523,9 @@ class ConvLSTM(HipBackbone):
         dev = prognostic.device
         hs = [torch.zeros(b, n, hgt, wid, device=dev) for n in self.hidden_sizes]
         cs = [torch.zeros(b, n, hgt, wid, device=dev) for n in self.hidden_sizes]
-        out = torch.empty(b, t_total - ctx, cg, hgt, wid, device=dev, dtype=torch.float32)
+        grad = self._grad_mode()       # training: nothing in place, the trajectory is stacked at the end
+        outs = []
+        out = None if grad else torch.empty(b, t_total - ctx, cg, hgt, wid, device=dev, dtype=torch.float32)
         prev = None
         for t in range(t_total):
             prog_t = prognostic[:, t] if t < ctx else prev
@@ -528,16 +540,22 @@ class ConvLSTM(HipBackbone):
                 hs[i], cs[i] = ops.convlstm_gates(cell.gates(x, hs[i]), cs[i])
                 x = hs[i]
             inc = self._decode(x)
-            if t >= ctx:
+            if grad:
+                prev = prog_t + inc
+                if t >= ctx:
+                    outs.append(prev)
+            elif t >= ctx:
                 torch.add(prog_t, inc, out=out[:, t - ctx])
                 prev = out[:, t - ctx]
             else:
                 prev = prog_t + inc
-        return out
+        return torch.stack(outs, dim=1) if grad else out
 
     def forward(self, constants: Optional[torch.Tensor] = None, prescribed: Optional[torch.Tensor] = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
         constants, prescribed, prognostic = self._check_inputs(constants, prescribed, prognostic)
+        if self._grad_mode():
+            return self._rollout(constants, prescribed, prognostic)
         with torch.no_grad():
             return self._rollout(constants, prescribed, prognostic)
 
@@ -565,10 +583,8 @@ class ConvLSTMHPX(ConvLSTM):
                     raise _lib.DlwpError(f"{name}: expected [B, T, C, 12, H, W], got {tuple(t.shape)}")
         if prognostic is None:
             raise _lib.DlwpError("prognostic is required")
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training is a 'next' row (SURVEY.md 8f f4); call .eval() / no_grad()")
         b, t_total, cg, f, h, w = prognostic.shape
-        with torch.no_grad():
+        with torch.set_grad_enabled(self._grad_mode()):
             fold5 = lambda t: t.permute(0, 3, 1, 2, 4, 5).reshape(b * f, t.shape[1], t.shape[2], h, w).float().contiguous()
             out = self._rollout(fold5(constants) if constants is not None else None,
                                 fold5(prescribed) if prescribed is not None else None, fold5(prognostic))

@@ -54,6 +54,9 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table:
     forms = {"fp32": spec.form, "fp32_mfma": 0, "bf16x6": 1, "bf16": -1}
     if precision not in forms:
         raise _lib.DlwpError(f"unknown attention precision {precision!r}")
+    from . import training as _T
+    if _T.wants_grad(qkv, qkv_bias, table) and not count_fallbacks:
+        return _T.window_attention(qkv, qkv_bias, table, spec, precision)     # HIP forward, differentiable (training.py)
     _lib.require_cuda_tensor(qkv, "qkv")
     _lib.require_cuda_tensor(table, "bias table")
     _lib.require_cuda_tensor(qkv_bias, "qkv bias")
@@ -106,6 +109,9 @@ def act_code(activation) -> int:
 def conv3x3_cyl(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
                 x1: Optional[torch.Tensor] = None) -> torch.Tensor:
     """CylinderPad(1) + Conv2d(3x3) + bias + activation on cat([x0, x1], 1) without the cat."""
+    from . import training as _T
+    if _T.wants_grad(x0, x1, weight, bias):
+        return conv3x3(x0, weight, bias, act=act, x1=x1)
     _lib.require_cuda_tensor(x0, "x0")
     _lib.require_cuda_tensor(x1, "x1")
     _lib.require_cuda_tensor(weight, "weight")
@@ -130,6 +136,9 @@ def conv3x3_hpx(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                 x1: Optional[torch.Tensor] = None) -> torch.Tensor:
     """HEALPixPadding(1) + Conv2d(3x3) + bias + activation on cat([x0, x1], 1); x [(B*12), C, H, W]."""
     from . import healpix as _hpx
+    from . import training as _T
+    if _T.wants_grad(x0, x1, weight, bias):
+        return conv3x3(x0, weight, bias, act=act, x1=x1, hpx=True)
 
     _lib.require_cuda_tensor(x0, "x0")
     _lib.require_cuda_tensor(x1, "x1")
@@ -162,6 +171,9 @@ def conv3x3(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]
     `resid` added before `act`; padding rule: CylinderPad, or HEALPixPadding when hpx (x [(B*12), C, H, W])."""
     for t, n in ((x0, "x0"), (x1, "x1"), (weight, "weight"), (resid, "resid")):
         _lib.require_cuda_tensor(t, n)
+    from . import training as _T
+    if _T.wants_grad(x0, x1, weight, bias, resid):
+        return _T.conv3x3(x0, weight, bias, act=act, x1=x1, pre_act=pre_act, resid=resid, hpx=hpx)   # HIP forward, differentiable
     x0 = x0.contiguous()
     x1 = x1.contiguous() if x1 is not None else None
     weight = weight.contiguous()
@@ -194,6 +206,9 @@ def groupnorm_act(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optiona
                   eps: float = 1e-5, act: int = 0) -> torch.Tensor:
     """act(GroupNorm(groups)(x)) for x [N, C, ...] (reference unet.py:739 + :761, :887-888), one launch."""
     _lib.require_cuda_tensor(x, "x")
+    from . import training as _T
+    if _T.wants_grad(x, weight, bias):
+        return _T._ACT_FNS[int(act)](torch.nn.functional.group_norm(x, int(groups), weight, bias, eps))
     x = x.contiguous()
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
@@ -212,6 +227,10 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     """zero-padded Conv2d (square kernel / stride / padding): the strided and 1x1 convolutions of unet.py:583-584, :879, :450."""
     for t, n in ((x, "x"), (weight, "weight"), (resid, "resid")):
         _lib.require_cuda_tensor(t, n)
+    from . import training as _T
+    if _T.wants_grad(x, weight, bias, resid):
+        y = torch.nn.functional.conv2d(_T._ACT_FNS[int(pre_act)](x), weight, bias, stride=stride, padding=padding)
+        return _T._ACT_FNS[int(act)](y if resid is None else y + resid)
     x, weight = x.contiguous(), weight.contiguous()
     n, cin, h, w = x.shape
     cout, cin_w, k, k2 = weight.shape
@@ -234,6 +253,9 @@ def conv_transpose2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
     """ConvTranspose2d (weight [cin, cout, k, k]; unet.py:523 2x2 s2, :719 4x4 s2 p1)."""
     _lib.require_cuda_tensor(x, "x")
     _lib.require_cuda_tensor(weight, "weight")
+    from . import training as _T
+    if _T.wants_grad(x, weight, bias):
+        return _T._ACT_FNS[int(act)](torch.nn.functional.conv_transpose2d(x, weight, bias, stride=stride, padding=padding))
     x, weight = x.contiguous(), weight.contiguous()
     n, cin, h, w = x.shape
     cin_w, cout, k, k2 = weight.shape
@@ -253,6 +275,8 @@ def conv_transpose2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
 def avgpool2x2(x: torch.Tensor) -> torch.Tensor:
     """AvgPool2d(kernel_size=2, stride=2) (unet.py:450)."""
     _lib.require_cuda_tensor(x, "x")
+    if torch.is_grad_enabled() and x.requires_grad:
+        return torch.nn.functional.avg_pool2d(x, 2)
     x = x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=torch.float32)
@@ -295,6 +319,11 @@ def healpix_pad(x: torch.Tensor, padding: int) -> torch.Tensor:
     if n % 12:
         raise _lib.DlwpError(f"leading dimension {n} is not (batch * 12 faces)")
     table = _hpx.device_table(h, w, int(padding), x.device)
+    if torch.is_grad_enabled() and x.requires_grad:
+        if int(padding) != 1:
+            raise _lib.DlwpError("differentiable HEALPix padding is built for padding 1")
+        from . import training as _T
+        return _T._hpx_pad_torch(x, table)
     y = torch.empty(n, c, h + 2 * padding, w + 2 * padding, device=x.device, dtype=torch.float32)
     lib = _lib.load()
     with torch.cuda.device(x.device):
@@ -306,6 +335,10 @@ def healpix_pad(x: torch.Tensor, padding: int) -> torch.Tensor:
 def convlstm_gates(gates: torch.Tensor, c_prev: torch.Tensor):
     _lib.require_cuda_tensor(gates, "gates")
     _lib.require_cuda_tensor(c_prev, "c_prev")
+    if torch.is_grad_enabled() and (gates.requires_grad or c_prev.requires_grad):     # convlstm.py:96-109 with torch operators
+        netin, ig, fg, og = torch.split(gates, gates.shape[1] // 4, dim=1)
+        c_new = torch.sigmoid(fg) * c_prev + torch.sigmoid(ig) * torch.tanh(netin)
+        return torch.sigmoid(og) * torch.tanh(c_new), c_new
     gates, c_prev = gates.contiguous(), c_prev.contiguous()
     b, c4, h, w = gates.shape
     hid = c4 // 4
@@ -392,6 +425,9 @@ def afno2d_filter_cf(x_cf: torch.Tensor, w1, b1, w2, b2, num_blocks: int, sparsi
     1/sqrt(HW) factors of norm="ortho"), the hand-written inverse transform.  Grids that are not instantiated (and
     use_rocfft=True, the cross-check) take the hipFFT path on the full half spectrum."""
     _lib.require_cuda_tensor(x_cf, "x_cf")
+    from . import training as _T
+    if _T.wants_grad(x_cf, w1, b1, w2, b2):
+        return _T.afno_filter(x_cf, w1, b1, w2, b2, num_blocks, sparsity_threshold, hard_thresholding_fraction)
     x_cf = x_cf.contiguous()
     b, c, h, w = x_cf.shape
     lib = _lib.load()
@@ -599,6 +635,9 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
                pre_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """LayerNorm over the last dimension (any leading shape); pre_bias [C] is added to x before the statistics."""
     _lib.require_cuda_tensor(x, "x")
+    from . import training as _T
+    if _T.wants_grad(x, weight, bias, pre_bias):     # training: the pointwise layers are torch operators (training.py)
+        return torch.nn.functional.layer_norm(x if pre_bias is None else x + pre_bias, (x.shape[-1],), weight, bias, eps)
     x = x.contiguous()
     c = x.shape[-1]
     rows = x.numel() // c

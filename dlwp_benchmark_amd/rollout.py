@@ -44,3 +44,17 @@ def rollout_into(one_step: Callable[[torch.Tensor], torch.Tensor], context_size:
         inc = one_step(x_t)
         torch.add(frames[-1], inc, out=out[:, s])
     return out
+
+
+def rollout_train(one_step: Callable[[torch.Tensor], torch.Tensor], context_size: int, constants: Optional[torch.Tensor],
+                  prescribed: Optional[torch.Tensor], prognostic: torch.Tensor) -> torch.Tensor:
+    """The same loop with autograd alive (reference scripts/train.py:263-271 trains through it): nothing in place, the
+    trajectory is stacked once at the end."""
+    ctx = context_size
+    outs = []
+    for s in range(prognostic.shape[1] - ctx):
+        t = s + ctx
+        frames = [prognostic[:, f] if f < ctx else outs[f - ctx] for f in range(s, t)]
+        x_t = assemble_input(constants, prescribed[:, t - ctx:t] if prescribed is not None else None, frames)
+        outs.append(frames[-1] + one_step(x_t))
+    return torch.stack(outs, dim=1)

@@ -134,3 +134,246 @@ def pde_arena_rows(height: int, modes1: int):
     """Kept rows of reference unet.py:60-65 (`[:m1]` with weights1, `[-m1:]` with weights2)."""
     rows = list(range(modes1)) + list(range(height - modes1, height))
     return rows, rows
+
+
+# =====================================================================================================================
+# Training through the other hot kernels (SURVEY.md 8f f4; reference scripts/train.py:263-271 `loss.backward()`)
+#
+# The boundary requires a differentiable forward (SURVEY.md 8b: "wrap kernels in autograd.Function with a PyTorch-op
+# backward").  For window attention, the AFNO filter and the padded 3x3 convolution the FORWARD of a training step runs
+# the same HIP kernels as inference; the BACKWARD recomputes the operator from the saved inputs with torch operators on
+# the GPU (a plain restatement of the reference arithmetic, below) and lets autograd differentiate that.  Nothing here
+# imports the oracle: these restatements are part of the product and double as an independent cross-check of the
+# kernels (tests/test_training_gpu.py).  Hand-written backward kernels are the next step; the spectral convolution
+# already has one (above).
+# =====================================================================================================================
+import functools
+
+import torch.nn.functional as F
+
+_ACT_FNS = {0: lambda t: t, 1: F.gelu, 2: torch.tanh, 3: F.relu, 4: F.silu}
+
+
+@functools.lru_cache(maxsize=64)
+def _window_tables(grid, padded, pad_lead, window, shift_fwd, use_mask, mask_b1, mask_b2, bias_mode, device_str):
+    """bias index [N, N] (long) and region ids [n_pl, n_lat, n_lon, N] of one window geometry, on the device."""
+    dev = torch.device(device_str)
+    wpl, wlat, wlon = window
+    n = wpl * wlat * wlon
+    z = torch.arange(n)
+    zlon, zlat, zpl = z % wlon, (z // wlon) % wlat, z // (wlon * wlat)
+    q, k = slice(None), slice(None)
+    if bias_mode == 0:
+        idx = (zlat[:, None] - zlat[None, :] + wlat - 1) * (2 * wlon - 1) + (zlon[:, None] - zlon[None, :] + wlon - 1)
+    else:   # earth-specific (utils/earth_position_index.py): query coordinate + window * key coordinate, relative longitude
+        idx = ((zpl[:, None] + zpl[None, :] * wpl) * wlat * wlat + (zlat[:, None] + zlat[None, :] * wlat)) * (2 * wlon - 1) + \
+              (zlon[:, None] - zlon[None, :] + wlon - 1)
+    npl, nlat, nlon = padded[0] // wpl, padded[1] // wlat, padded[2] // wlon
+    region = None
+    if use_mask:
+        P = (torch.arange(npl)[:, None] * wpl + zpl[None, :])          # [npl, N]
+        A = (torch.arange(nlat)[:, None] * wlat + zlat[None, :])
+        O = (torch.arange(nlon)[:, None] * wlon + zlon[None, :])
+        rp = (P >= mask_b1[0]).long() + (P >= mask_b2[0]).long()
+        ra = (A >= mask_b1[1]).long() + (A >= mask_b2[1]).long()
+        ro = (O >= mask_b1[2]).long() + (O >= mask_b2[2]).long()
+        region = ((rp[:, None, None, :] * 3 + ra[None, :, None, :]) * 3 + ro[None, None, :, :]).to(dev)
+    return idx.to(dev), region
+
+
+def window_attention_torch(qkv: torch.Tensor, qkv_bias, table: torch.Tensor, spec) -> torch.Tensor:
+    """What dlwp_window_attn_f32 computes, with torch operators (differentiable in qkv, qkv_bias, table):
+    swin_transformer.py:217-251 + :122-154 (bias_mode 0) / panguweather.py:285-316 + :176-211 (bias_mode 1)."""
+    b, l, c3 = qkv.shape
+    heads, d = spec.heads, spec.head_dim
+    c = heads * d
+    pl, lat, lon = spec.grid
+    ppl, plat, plon = spec.padded
+    wpl, wlat, wlon = spec.window
+    x = qkv.view(b, pl, lat, lon, c3)
+    f, t, lft = spec.pad_lead
+    pads = (0, 0, lft, plon - lon - lft, t, plat - lat - t, f, ppl - pl - f)
+    if any(pads):
+        # zero-padded tokens enter the qkv Linear as zeros: their q, k, v are the bias
+        x = F.pad(x - qkv_bias, pads) + qkv_bias
+    sf = tuple(int(s) for s in spec.shift_fwd)
+    if any(sf):
+        x = torch.roll(x, shifts=(-sf[0], -sf[1], -sf[2]), dims=(1, 2, 3))
+    npl, nlat, nlon = ppl // wpl, plat // wlat, plon // wlon
+    n = wpl * wlat * wlon
+    x = x.view(b, npl, wpl, nlat, wlat, nlon, wlon, 3, heads, d).permute(0, 1, 3, 5, 7, 8, 2, 4, 6, 9)
+    x = x.reshape(b, npl, nlat, nlon, 3, heads, n, d)
+    q, k, v = x[:, :, :, :, 0] * spec.scale, x[:, :, :, :, 1], x[:, :, :, :, 2]
+    idx, region = _window_tables(tuple(spec.grid), tuple(spec.padded), tuple(spec.pad_lead), tuple(spec.window), sf,
+                                 bool(spec.use_mask), tuple(int(v_) for v_ in spec.mask_b1),
+                                 tuple(int(v_) for v_ in spec.mask_b2), int(spec.bias_mode), str(qkv.device))
+    attn = q @ k.transpose(-1, -2)                                      # [b, npl, nlat, nlon, heads, N, N]
+    if spec.bias_mode == 0:
+        bias = table[idx.reshape(-1)].view(n, n, heads).permute(2, 0, 1)                    # [heads, N, N]
+        attn = attn + bias
+    else:
+        types = npl * nlat
+        bias = table[idx.reshape(-1)].view(n, n, types, heads).permute(2, 3, 0, 1)          # [types, heads, N, N]
+        attn = attn + bias.view(npl, nlat, 1, heads, n, n)
+    if spec.use_mask:
+        diff = region.unsqueeze(-1) != region.unsqueeze(-2)                                  # [npl, nlat, nlon, N, N]
+        attn = attn + torch.where(diff, -100.0, 0.0).to(attn.dtype).unsqueeze(3)
+    attn = torch.softmax(attn, dim=-1)
+    o = attn @ v                                                       # [b, npl, nlat, nlon, heads, N, d]
+    o = o.view(b, npl, nlat, nlon, heads, wpl, wlat, wlon, d).permute(0, 1, 5, 2, 6, 3, 7, 4, 8)
+    o = o.reshape(b, ppl, plat, plon, c)
+    sb = tuple(int(s) for s in spec.shift_back)
+    if any(sb):
+        o = torch.roll(o, shifts=sb, dims=(1, 2, 3))
+    o = o[:, f:f + pl, t:t + lat, lft:lft + lon]
+    return o.reshape(b, l, c)
+
+
+class _WindowAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, table, spec, precision):
+        from . import ops
+
+        ctx.spec = spec
+        ctx.save_for_backward(qkv, qkv_bias, table)
+        with torch.no_grad():
+            return ops.window_attention(qkv.detach(), qkv_bias.detach() if qkv_bias is not None else None,
+                                        table.detach(), spec, precision=precision)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        qkv, qkv_bias, table = ctx.saved_tensors
+        with torch.enable_grad():
+            q_ = qkv.detach().requires_grad_(ctx.needs_input_grad[0])
+            b_ = qkv_bias.detach().requires_grad_(ctx.needs_input_grad[1]) if qkv_bias is not None else None
+            t_ = table.detach().requires_grad_(ctx.needs_input_grad[2])
+            out = window_attention_torch(q_, b_, t_, ctx.spec)
+            wrt = [t for t, need in ((q_, ctx.needs_input_grad[0]), (b_, ctx.needs_input_grad[1]), (t_, ctx.needs_input_grad[2]))
+                   if need and t is not None]
+            grads = list(torch.autograd.grad(out, wrt, grad_out.contiguous(), allow_unused=True)) if wrt else []
+        res = []
+        for t, need in ((q_, ctx.needs_input_grad[0]), (b_, ctx.needs_input_grad[1]), (t_, ctx.needs_input_grad[2])):
+            res.append(grads.pop(0) if (need and t is not None) else None)
+        return res[0], res[1], res[2], None, None
+
+
+def window_attention(qkv, qkv_bias, table, spec, precision="fp32"):
+    """differentiable window attention: HIP forward, recomputed torch backward"""
+    return _WindowAttentionFn.apply(qkv, qkv_bias, table, spec, precision)
+
+
+def afno_filter_torch(x_cf, w1, b1, w2, b2, num_blocks: int, sparsity_threshold: float, hard_thresholding_fraction: float):
+    """fourcastnet.py:85-124 on a CHANNELS-FIRST field (without the `+ bias` of :127), torch operators."""
+    b, c, h, w = x_cf.shape
+    bs = c // num_blocks
+    xf = torch.fft.rfft2(x_cf.float(), norm="ortho")                               # [b, c, h, wf]
+    xf = xf.permute(0, 2, 3, 1).reshape(b, h, w // 2 + 1, num_blocks, bs)
+    total = h // 2 + 1
+    kept = int(total * hard_thresholding_fraction)
+    rows = slice(max(total - kept, 0), min(total + kept, h))
+    xr, xi = xf.real[:, rows, :kept], xf.imag[:, rows, :kept]
+    ein = lambda a, m: torch.einsum("...bi,bio->...bo", a, m)
+    o1r = F.relu(ein(xr, w1[0]) - ein(xi, w1[1]) + b1[0])
+    o1i = F.relu(ein(xi, w1[0]) + ein(xr, w1[1]) + b1[1])
+    o2r = ein(o1r, w2[0]) - ein(o1i, w2[1]) + b2[0]
+    o2i = ein(o1i, w2[0]) + ein(o1r, w2[1]) + b2[1]
+    z = F.softshrink(torch.stack([o2r, o2i], dim=-1), lambd=sparsity_threshold)
+    full = torch.zeros(b, h, w // 2 + 1, num_blocks, bs, 2, device=x_cf.device, dtype=torch.float32)
+    full = _put(full, rows, kept, z)
+    yf = torch.view_as_complex(full).reshape(b, h, w // 2 + 1, c).permute(0, 3, 1, 2)
+    return torch.fft.irfft2(yf, s=(h, w), norm="ortho")
+
+
+def _put(full, rows, kept, z):
+    full = full.clone()
+    full[:, rows, :kept] = z
+    return full
+
+
+class _AfnoFilterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cf, w1, b1, w2, b2, num_blocks, lam, frac):
+        from . import ops
+
+        ctx.cfg = (num_blocks, lam, frac)
+        ctx.save_for_backward(x_cf, w1, b1, w2, b2)
+        with torch.no_grad():
+            return ops.afno2d_filter_cf(x_cf.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), num_blocks, lam, frac)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved = ctx.saved_tensors
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(need) for t, need in zip(saved, ctx.needs_input_grad[:5])]
+            out = afno_filter_torch(*ins, *ctx.cfg)
+            wrt = [t for t, need in zip(ins, ctx.needs_input_grad[:5]) if need]
+            grads = list(torch.autograd.grad(out, wrt, grad_out.contiguous(), allow_unused=True)) if wrt else []
+        res = [grads.pop(0) if need else None for need in ctx.needs_input_grad[:5]]
+        return (*res, None, None, None)
+
+
+def afno_filter(x_cf, w1, b1, w2, b2, num_blocks, lam, frac):
+    return _AfnoFilterFn.apply(x_cf, w1, b1, w2, b2, num_blocks, lam, frac)
+
+
+def _hpx_pad_torch(x, table):
+    """HEALPixPadding(1) as a differentiable gather: x [(B*12), C, H, W], table int32 [12, (H+2)(W+2), 2]."""
+    n, c, h, w = x.shape
+    bsz = n // 12
+    flat = x.view(bsz, 12, c, h * w).permute(0, 2, 1, 3).reshape(bsz, c, 12 * h * w)
+    a = table[:, :, 0].long().reshape(-1)
+    b_ = table[:, :, 1].long().reshape(-1)
+    va = flat[:, :, a]
+    vb = flat[:, :, b_.clamp(min=0)]
+    v = torch.where((b_ >= 0).view(1, 1, -1), 0.5 * va + 0.5 * vb, va)
+    return v.view(bsz, c, 12, h + 2, w + 2).permute(0, 2, 1, 3, 4).reshape(n, c, h + 2, w + 2)
+
+
+def conv3x3_torch(x0, x1, weight, bias, resid, pre_act: int, act: int, hpx_table=None):
+    """pad(1) + Conv2d(3x3) (+ fusions) with torch operators: CylinderPad (utils/utils.py:11-26) or HEALPixPadding."""
+    x = x0 if x1 is None else torch.cat([x0, x1], dim=1)
+    x = _ACT_FNS[pre_act](x)
+    if hpx_table is not None:
+        x = _hpx_pad_torch(x, hpx_table)
+    else:
+        x = F.pad(F.pad(x, (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1))
+    y = F.conv2d(x, weight, bias)
+    if resid is not None:
+        y = y + resid
+    return _ACT_FNS[act](y)
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, resid, pre_act, act, hpx):
+        from . import ops
+
+        ctx.cfg = (pre_act, act, hpx)
+        ctx.save_for_backward(x0, x1, weight, bias, resid)
+        with torch.no_grad():
+            d = lambda t: t.detach() if t is not None else None
+            return ops.conv3x3(d(x0), d(weight), d(bias), act=act, x1=d(x1), pre_act=pre_act, resid=d(resid), hpx=hpx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import healpix as _hpx
+
+        pre_act, act, hpx = ctx.cfg
+        saved = ctx.saved_tensors
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(need) if t is not None else None for t, need in zip(saved, ctx.needs_input_grad[:5])]
+            table = _hpx.device_table(ins[0].shape[2], ins[0].shape[3], 1, ins[0].device) if hpx else None
+            out = conv3x3_torch(ins[0], ins[1], ins[2], ins[3], ins[4], pre_act, act, table)
+            wrt = [t for t, need in zip(ins, ctx.needs_input_grad[:5]) if need and t is not None]
+            grads = list(torch.autograd.grad(out, wrt, grad_out.contiguous(), allow_unused=True)) if wrt else []
+        res = [grads.pop(0) if (need and t is not None) else None for t, need in zip(ins, ctx.needs_input_grad[:5])]
+        return (*res, None, None, None)
+
+
+def conv3x3(x0, weight, bias, act=0, x1=None, pre_act=0, resid=None, hpx=False):
+    return _Conv3x3Fn.apply(x0, x1, weight, bias, resid, pre_act, act, hpx)
+
+
+def wants_grad(*tensors) -> bool:
+    """True when autograd is recording and one of the tensors takes part: the ops then run their differentiable form."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -203,6 +203,59 @@ def gen_models(ref, only=None):
               param_spec=np.array(json.dumps(spec)), state_spec=np.array(json.dumps(full)))
 
 
+# ------------------------------------------------------------------------------------------
+# training row f4: gradients of a rollout MSE loss through the REAL classes (eval mode: stochastic depth off, the
+# gradient arithmetic is the one train.py:263-271 differentiates)
+# ------------------------------------------------------------------------------------------
+GRAD_CASES = {
+    # tag: (base MODEL_CASES entry, frames)
+    "swin_e32_32x64": ("swin_e32_32x64", 3),
+    "afno_e16_32x64": ("afno_e16_32x64", 2),      # one step: the reference's in-model loop breaks on the second
+    "pangu_e48_32x64": ("pangu_e48_32x64", 2),
+    "unet_h4_32x64": ("unet_h4_32x64", 3),
+    "convlstm_h8_32x64": ("convlstm_h8_32x64", 4),
+}
+
+
+def grad_probe(tag, name, shape):
+    """fixed pseudo-random direction a parameter gradient is projected on (same on every machine)"""
+    return W.normal(f"golden/grad/{tag}/{name}", tuple(shape), 1.0)
+
+
+def rollout_mse(y, prognostic, ctx):
+    return torch.mean((y - prognostic[:, ctx:ctx + y.shape[1]]) ** 2)
+
+
+def gen_grads(ref, only=None):
+    import json
+
+    for tag, (base, frames) in GRAD_CASES.items():
+        if only and tag not in only:
+            continue
+        family, cfg, (batch, _), gain = MODEL_CASES[base]
+        m = build_reference(ref, family, cfg)
+        sha = W.fill_state_dict(m, gain=gain)
+        constants, prescribed, prognostic = model_inputs(base, cfg, batch, frames)
+        for p_ in m.parameters():
+            p_.requires_grad_(True)
+        y = m(constants=constants, prescribed=prescribed, prognostic=prognostic)
+        loss = rollout_mse(y, prognostic, cfg["context_size"])
+        loss.backward()
+        names, norms, projs = [], [], []
+        full = {}
+        for name, p_ in m.named_parameters():
+            if p_.grad is None:
+                continue
+            g = p_.grad.detach().double()
+            names.append(name)
+            norms.append(float(g.norm()))
+            projs.append(float((g * grad_probe(tag, name, g.shape).double()).sum()))
+            if p_.numel() <= 4096 and len(full) < 6:
+                full["grad::" + name] = p_.grad.detach().numpy().astype(np.float32)
+        _save(f"grad_{tag}", names=np.array(json.dumps(names)), norms=np.array(norms), projs=np.array(projs),
+              loss=np.array(float(loss)), sha=np.array(sha), **full)
+
+
 def gen_horizons(ref, only=None):
     for tag, (base, frames, stride) in HORIZON_CASES.items():
         if only and tag not in only:
@@ -327,7 +380,9 @@ def main():
         gen_spectral(ref)
     if not only or "hpx" in only:
         gen_hpx(ref)
-    rest = only - {"spectral", "hpx"} - set(HORIZON_CASES) - {"horizons"}
+    rest = only - {"spectral", "hpx", "grads", "horizons"} - set(HORIZON_CASES)
+    if not only or "grads" in only:
+        gen_grads(ref, None)
     if not only or rest:
         gen_models(ref, rest if only else None)
     if not only or "horizons" in only or (only & set(HORIZON_CASES)):

@@ -75,3 +75,82 @@ def test_fno_training_step_matches_oracle_autograd():
         gc = torch.view_as_real(grads_c[k]) if grads_c[k].is_complex() else grads_c[k]
         assert rel_l2(gg, gc) < 1e-4, k
     assert rel_l2(after_g, after_c) < 1e-4
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# row f4 for the other backbones: rollout-MSE gradients through the product in train mode vs gradients the REAL reference
+# classes produced (tests/golden/grad_*.npz, oracle/make_golden.py gen_grads).  Tolerance 1e-4.
+# -----------------------------------------------------------------------------------------------------------------
+import json
+
+import numpy as np
+
+from helpers import load_golden
+
+
+def _grad_cases():
+    from oracle.make_golden import GRAD_CASES
+
+    return list(GRAD_CASES)
+
+
+@pytest.mark.parametrize("tag", _grad_cases())
+def test_training_gradients_match_reference(tag):
+    import dlwp_benchmark_amd.models as M
+    from dlwp_benchmark_amd.weights import fill_state_dict
+    from oracle.make_golden import GRAD_CASES, MODEL_CASES, grad_probe, model_inputs, rollout_mse
+
+    base, frames = GRAD_CASES[tag]
+    family, cfg, (batch, _), gain = MODEL_CASES[base]
+    name = {"swin": "SwinTransformer", "pangu": "PanguWeather", "afno": "FourCastNet", "unet": "UNet", "convlstm": "ConvLSTM"}[family]
+    g = load_golden(f"grad_{tag}")
+    model = getattr(M, name)(**cfg)
+    sha = fill_state_dict(model, gain=gain)
+    assert sha == str(g["sha"]), "filler drifted: regenerate fixtures"
+    model = model.to("cuda:0")
+    assert model.train() is model
+    dev = lambda t: t.to("cuda:0") if t is not None else None
+    constants, prescribed, prognostic = [dev(t) for t in model_inputs(base, cfg, batch, frames)]
+    y = model(constants=constants, prescribed=prescribed, prognostic=prognostic)        # train.py:263-267
+    assert y.requires_grad
+    loss = rollout_mse(y, prognostic, cfg["context_size"])
+    loss.backward()                                                                     # train.py:271
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    names = json.loads(str(g["names"]))
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for i, pname in enumerate(names):
+        assert pname in params and params[pname].grad is not None, f"no gradient for {pname}"
+        gr = params[pname].grad.detach().double().cpu()
+        n_ref, p_ref = float(g["norms"][i]), float(g["projs"][i])
+        scale = max(n_ref, 1e-12)
+        worst = max(worst, abs(float(gr.norm()) - n_ref) / scale)
+        # projection on a fixed random direction: |<g, r> - ref| relative to |g| |r|
+        r = grad_probe(tag, pname, gr.shape).double()
+        worst = max(worst, abs(float((gr * r).sum()) - p_ref) / (scale * float(r.norm())))
+    for key in g.files:
+        if key.startswith("grad::"):
+            want = torch.from_numpy(g[key]).double()
+            got = params[key[6:]].grad.detach().double().cpu()
+            worst = max(worst, float((got - want).norm() / want.norm().clamp_min(1e-30)))
+    print(tag, "worst relative gradient deviation:", "%.2e" % worst)
+    assert worst <= 1e-4
+
+
+def test_differentiable_restatements_match_the_kernels():
+    """The torch forms the backward passes differentiate (training.py) are the same operators as the HIP kernels."""
+    from dlwp_benchmark_amd import ops, training as T
+    from test_window_attn_gpu import _inputs, _spec
+
+    for shifted in (False, True):
+        spec, rows = _spec(16, 32, 2, 8, shifted)
+        qkv, bias, table = _inputs(2, 16, 32, 2, 8, rows)
+        a = ops.window_attention(qkv, bias, table, spec, precision="fp32_mfma")
+        b = T.window_attention_torch(qkv, bias, table, spec)
+        assert float((a - b).norm() / b.norm()) <= 2e-6
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 32, 64, generator=gen).cuda()
+    w1, b1, w2, b2 = [(0.3 * torch.randn(*s, generator=gen)).cuda() for s in ((2, 4, 4, 4), (2, 4, 4), (2, 4, 4, 4), (2, 4, 4))]
+    a = ops.afno2d_filter_cf(x, w1, b1, w2, b2, 4, 0.01, 1.0)
+    b = T.afno_filter_torch(x, w1, b1, w2, b2, 4, 0.01, 1.0)
+    assert float((a - b).norm() / b.norm()) <= 2e-6
