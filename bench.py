@@ -51,6 +51,7 @@ def build_model(device):
 
     m = FNO2DModule(**MODEL_KW)
     sha = fill_state_dict(m, std_fn=std_fn, gain=0.85)
+    m.set_execution_form(check="deferred")      # asynchronous rollouts, verified by model.verify() in finish()
     return m.to(device).eval(), sha
 
 
@@ -393,6 +394,9 @@ def main():
         return out
 
     def finish():
+        # deferred verification of every fused launch since the last call (DLWP_ERR_TIMEOUT raises here): the rollouts of an
+        # evaluation are enqueued asynchronously and verified ONCE, inside the timed region
+        model.verify()
         # the ONE collective of the sharded evaluation: all-reduce of [4, K, C] sums + sample count (inside the timed region)
         if args.collect == "metrics" and acc["sums"] is not None:
             scores["last"] = scorer.finalize(acc["sums"], float(acc["samples"]), H * W, world_size=world)
@@ -440,6 +444,7 @@ def main():
                                                           "none": "no collective"}[args.collect])
             if world > 1 else "single GPU",
             "collect": args.collect,
+            "fused_kernel_check": "deferred: rollouts enqueued asynchronously, verified once per evaluation inside the timed region",
             "weights": "deterministic filler sha256:" + sha[:16],
         },
     }

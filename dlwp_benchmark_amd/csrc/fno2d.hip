@@ -1170,7 +1170,8 @@ struct TrunkParams {
   // hand-off bounds (plan knobs): polls of a counter barrier / re-loads of a flag-in-data block before the workgroup
   // gives up; a workgroup that gives up poisons its outputs with NaN AND sets *fail_word (checked by the host)
   int spin_limit, try_limit;
-  unsigned* fail_word;
+  unsigned* fail_word;     // workspace word, zeroed at the start of every call (per-call check)
+  unsigned* sticky_fails;  // plan-owned counter, only reset by dlwp_fno2d_status (deferred check of asynchronous calls)
 };
 
 __device__ __forceinline__ void trunk_group_barrier(unsigned* ctr, unsigned target, int* s_fail, int spin_limit) {
@@ -1840,7 +1841,10 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #undef DLWP_STAMP
   if (*s_fail) {
     // loud failure: the host reads this word after the launch (DLWP_ERR_TIMEOUT / re-run on the unfused kernels)
-    if (tid == 0 && p.fail_word) __hip_atomic_store(p.fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && p.fail_word) {
+      __hip_atomic_store(p.fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(p.sticky_fails, 1u);   // (per poisoned step of a workgroup: any non-zero value means failure)
+    }
     const float nanv = __uint_as_float(0x7fc00000u);
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -2145,6 +2149,7 @@ static int env_int(const char* name, int dflt) {
 struct dlwp_fno2d_plan {
   FnoKnobs k;
   mutable std::atomic<unsigned> timeouts{0};   // statistics only: fused launches that timed out (re-run or reported)
+  DevBuf sticky;                               // device word the fused kernels add to on a timeout (reset by dlwp_fno2d_status)
   int cin = 0, hid_l = 0, hid_p = 0, cout = 0, L = 0, H = 0, W = 0;
   int cin_steps = 0;
   SpectralCore sc;
@@ -2353,6 +2358,12 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
   if (e != hipSuccess) {
     delete p;
     return fail(DLWP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+  }
+  {
+    const unsigned zero = 0;
+    hipError_t se = p->sticky.upload(&zero, 4, s);
+    if (se == hipSuccess) se = hipStreamSynchronize(s);
+    if (se != hipSuccess) { delete p; return fail(DLWP_ERR_HIP, "plan allocation failed: %s", hipGetErrorString(se)); }
   }
   // Residency of the fused kernels (8-row workgroups, 512 threads, trunk_lds(8) bytes of LDS): the hand-offs spin on
   // peer workgroups, so a launch may only hold as many workgroups as the occupancy query admits per CU x CUs.  A
@@ -2588,6 +2599,7 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
     tp.xcc_tab = ws.ctr + align_up((size_t)B * kCtrStrideBytes, 256) / 4 + (size_t)s0 * 32;
     tp.H = p->H; tp.L = p->L; tp.M1 = p->sc.M1; tp.M2 = p->sc.M2; tp.G = G; tp.sample0 = s0;
     tp.spin_limit = p->k.spin_limit; tp.try_limit = p->k.try_limit; tp.fail_word = ws.fail;
+    tp.sticky_fails = p->sticky.as<unsigned>();
     // diagnostics: DLWP_TRUNK_TRACE=<file> dumps per-workgroup phase timestamps of the first few launches
     static const char* trace_path = getenv("DLWP_TRUNK_TRACE");
     static unsigned long long* trace_buf = nullptr;
@@ -2839,16 +2851,19 @@ extern "C" int32_t dlwp_fno2d_forward_f32(const dlwp_fno2d_plan* plan, const flo
   return fail(DLWP_ERR_TIMEOUT, "unreachable: the unfused kernels have no hand-offs");
 }
 
-extern "C" int32_t dlwp_fno2d_status(const dlwp_fno2d_plan* plan, int32_t batch, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
-  DLWP_REQUIRE(plan && workspace && batch > 0, DLWP_ERR_INVALID_ARGUMENT, "null argument");
-  const FnoWorkspace ws = carve(plan, batch, workspace);
-  DLWP_REQUIRE(workspace_bytes >= ws.total, DLWP_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
-  const int f = read_fail_word(ws, reinterpret_cast<hipStream_t>(stream));
-  if (f < 0) return fail(DLWP_ERR_HIP, "reading the fused kernel's fail word failed");
-  if (f == 1) {
+extern "C" int32_t dlwp_fno2d_status(const dlwp_fno2d_plan* plan, void* stream) {
+  DLWP_REQUIRE(plan, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  thread_local unsigned* h_word = nullptr;   // pinned, one per host thread; never freed
+  if (!h_word) DLWP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_word), 64, hipHostMallocDefault));
+  *h_word = 0u;
+  DLWP_HIP_CHECK(hipMemcpyAsync(h_word, plan->sticky.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  DLWP_HIP_CHECK(hipMemsetAsync(plan->sticky.p, 0, sizeof(unsigned), s));
+  DLWP_HIP_CHECK(hipStreamSynchronize(s));
+  if (*h_word) {
     plan->timeouts.fetch_add(1);
-    return fail(DLWP_ERR_TIMEOUT, "fused FNO launch: a workgroup hand-off exceeded its spin bound (output poisoned with NaN)");
+    return fail(DLWP_ERR_TIMEOUT, "fused FNO kernels: %u workgroup(s) exceeded a hand-off spin bound since the last status call "
+                "(outputs of those launches are poisoned with NaN)", *h_word);
   }
   return DLWP_OK;
 }

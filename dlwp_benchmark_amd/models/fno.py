@@ -172,10 +172,11 @@ class FNO2DModule(HipBackbone):
         self.precision_form = "bf16x6"   # or "fp32_mfma": plain fp32-MFMA kernels + unfused spectral path (cross-check)
         self.launch_form = 0             # 0 fewest launches, 1 one per step, 2 three per step, 3 unfused kernels
         self.on_timeout = "rerun"        # or "raise": DLWP_ERR_TIMEOUT instead of the automatic re-run on the unfused kernels
+        self.check = "per_call"          # or "deferred": asynchronous calls, the caller verifies with .check() (see there)
         self._debug_spin_limit = 0       # test hook: tiny hand-off spin bound to force the timeout path
 
     def set_execution_form(self, precision_form: Optional[str] = None, launch_form: Optional[int] = None,
-                           on_timeout: Optional[str] = None):
+                           on_timeout: Optional[str] = None, check: Optional[str] = None):
         if precision_form is not None:
             if precision_form not in ("bf16x6", "fp32_mfma"):
                 raise _lib.DlwpError(f"unknown precision_form {precision_form!r}")
@@ -188,6 +189,20 @@ class FNO2DModule(HipBackbone):
             if on_timeout not in ("rerun", "raise"):
                 raise _lib.DlwpError(f"unknown on_timeout {on_timeout!r}")
             self.on_timeout = on_timeout
+        if check is not None:
+            if check not in ("per_call", "deferred"):
+                raise _lib.DlwpError(f"unknown check mode {check!r}")
+            self.check = check
+        return self
+
+    def verify(self):
+        """Deferred verification (`check="deferred"`): synchronises the current stream and raises DlwpError (status -5,
+        DLWP_ERR_TIMEOUT) if a fused launch of the current plan timed out since the last call of this method -- the
+        pattern for throughput evaluation: many asynchronous rollouts, one verification.  With the default
+        `check="per_call"` every call verifies (and repairs) itself and this is a no-op that always passes."""
+        if self._plan is not None:
+            with torch.cuda.device(next(self.parameters()).device):
+                _lib.check(_lib.load().dlwp_fno2d_status(self._plan, _lib.stream_ptr()), "dlwp_fno2d_status")
         return self
 
     def fused_timeouts(self) -> int:
@@ -211,7 +226,7 @@ class FNO2DModule(HipBackbone):
 
     def _get_plan(self, h: int, w: int, device):
         key = (h, w, str(device), self._param_key(), self.precision_form, self.launch_form, self.on_timeout,
-               self._debug_spin_limit)
+               self._debug_spin_limit, self.check)
         if self._plan is not None and key == self._plan_key:
             return self._plan
         self._destroy_plan()
@@ -264,7 +279,7 @@ class FNO2DModule(HipBackbone):
         d.precision_form = 1 if self.precision_form == "fp32_mfma" else 0
         d.launch_form = int(self.launch_form)
         d.on_timeout = 1 if self.on_timeout == "raise" else 0
-        d.unchecked = 0
+        d.unchecked = 1 if self.check == "deferred" else 0
         d.debug_spin_limit = int(self._debug_spin_limit)
         plan = ctypes.c_void_p()
         with torch.cuda.device(device):

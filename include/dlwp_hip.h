@@ -93,10 +93,10 @@ int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** plan, const dlwp_fno2d_desc* de
 int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan);
 /* bytes of device workspace one call needs for `batch` samples */
 size_t dlwp_fno2d_workspace_bytes(const dlwp_fno2d_plan* plan, int32_t batch);
-/* Synchronises `stream` and reports whether a fused launch enqueued on it since the last call's start timed out
- * (DLWP_ERR_TIMEOUT, outputs poisoned with NaN) -- for plans created with unchecked = 1. */
-int32_t dlwp_fno2d_status(const dlwp_fno2d_plan* plan, int32_t batch, void* workspace_dev, size_t workspace_bytes,
-                          void* stream);
+/* Deferred check for plans created with unchecked = 1 (fully asynchronous calls): synchronises `stream` and returns
+ * DLWP_ERR_TIMEOUT if any fused launch of this plan timed out since the previous status call (a plan-owned device counter
+ * the kernels add to; reset here).  The outputs of such launches are poisoned with NaN. */
+int32_t dlwp_fno2d_status(const dlwp_fno2d_plan* plan, void* stream);
 /* statistics: fused launches of this plan that timed out so far (re-run or reported) */
 uint32_t dlwp_fno2d_timeouts(const dlwp_fno2d_plan* plan);
 

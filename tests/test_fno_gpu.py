@@ -258,7 +258,17 @@ def test_fused_timeout_is_loud_and_falls_back():
     assert hip.fused_timeouts() == 1, "the forced timeout did not fire"
     assert torch.isfinite(got).all()
     assert max(per_step_rel_l2(got, want)) <= TOL
+    # deferred mode: asynchronous calls, ONE verification -- which must raise while the knob forces timeouts
+    hip.set_execution_form(check="deferred")
+    bad = hip(prognostic=p)
+    with pytest.raises(L.DlwpError, match="status -5"):
+        hip.verify()
+    assert not torch.isfinite(bad).all(), "a timed-out asynchronous launch must leave NaN in its output"
     hip._debug_spin_limit = 0
+    fine = hip(prognostic=p)
+    hip.verify()
+    assert torch.equal(fine, good)
+    hip.set_execution_form(check="per_call")
     again = hip(prognostic=p)
     assert hip.fused_timeouts() == 0 and torch.equal(again, good)
 
