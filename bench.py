@@ -381,15 +381,32 @@ def main():
     scorer = RolloutMetrics(torch.zeros(H))
     target = prog[:, model.context_size:].contiguous()
     scores = {}
-    acc = {"sums": None, "samples": 0}
+    acc = {"sums": torch.zeros(4, K_roll, prog.shape[2], dtype=torch.float64, device=device) if args.collect == "metrics" else None,
+           "samples": 0}
 
-    def step():
+    def step_eager():
         out = runner(prognostic=prog)
         if args.collect == "metrics":
             # this rank's squared-error sums of the rollout, ADDED to the evaluation's running sums on the device (the
             # reference accumulates over all batches before taking the root, evaluate.py:786-821): no collective per step
-            s = scorer.sums(out, target)
-            acc["sums"] = s if acc["sums"] is None else acc["sums"].add_(s)
+            acc["sums"].add_(scorer.sums(out, target))
+        return out
+
+    # One bench step (= one rollout of the batch + its metric sums) is a fixed chain of launches on fixed buffers: three
+    # workspace memsets, the persistent rollout kernel, the sums kernel, the accumulation.  It is captured ONCE into a HIP
+    # graph and replayed per step (launch gaps between the dependent nodes: ~1.5 us instead of ~6 us each).  Only without
+    # a collective inside the step (--collect gather issues RCCL calls per chunk) and with the deferred verification
+    # (a captured call cannot synchronise).  DLWP_BENCH_GRAPH=0 runs the same step eagerly.
+    use_graph = args.collect != "gather" and os.environ.get("DLWP_BENCH_GRAPH", "1") != "0"
+    graph = {"g": None, "out": None}
+
+    def step():
+        if graph["g"] is not None:
+            graph["g"].replay()
+            out = graph["out"]
+        else:
+            out = step_eager()
+        if args.collect == "metrics":
             acc["samples"] += B
         return out
 
@@ -401,10 +418,25 @@ def main():
         if args.collect == "metrics" and acc["sums"] is not None:
             scores["last"] = scorer.finalize(acc["sums"], float(acc["samples"]), H * W, world_size=world)
 
-    for _ in range(args.warmup):
-        out = step()
+    for _ in range(max(args.warmup, 1) if use_graph else args.warmup):
+        out = step()              # eager warm-up: plans, allocator
+    if use_graph:
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                graph["out"] = step_eager()
+            graph["g"] = g
+            for _ in range(2):
+                step()            # replay warm-up
+        except Exception as e:    # report, never hide: the line says which form ran
+            graph["g"], graph["out"] = None, None
+            use_graph = False
+            print(f"bench: HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
     finish()                      # also initialises the communicator's all-reduce path before the clock starts
-    acc["sums"], acc["samples"] = None, 0
+    if acc["sums"] is not None:
+        acc["sums"].zero_()
+    acc["samples"] = 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -445,6 +477,7 @@ def main():
             if world > 1 else "single GPU",
             "collect": args.collect,
             "fused_kernel_check": "deferred: rollouts enqueued asynchronously, verified once per evaluation inside the timed region",
+            "launch": "hip graph replay of one step (memsets + rollout kernel + metric sums)" if graph["g"] is not None else "eager",
             "weights": "deterministic filler sha256:" + sha[:16],
         },
     }

@@ -90,6 +90,10 @@ SIGNATURES = {
                                        c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dlwp_conv3x3_ex_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                       c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "dlwp_linear_packed_bytes": (c_size_t, [c_int32, c_int32]),
+    "dlwp_linear_pack_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "dlwp_linear_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32,
+                                  c_void_p]),
     "dlwp_groupnorm_act_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
                                          c_int32, c_void_p]),
     "dlwp_conv2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

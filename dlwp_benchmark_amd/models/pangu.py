@@ -97,6 +97,7 @@ class _EarthSpecificBlock(nn.Module):
         self.mlp = _Mlp(dim, int(dim * 4.0))
         self.roll = bool(self.shift_size[0] and self.shift_size[1] and self.shift_size[2])
         self.attention_precision = "fp32"
+        self.linear_form = "bf16x6"      # "bf16x6": dlwp_linear_f32; "rocblas": fp32 rocBLAS GEMMs (cross-check / A-B timing)
         self.register_buffer("attn_mask", _shift_mask(self.pad_resolution, self.window_size, self.shift_size)
                              if self.roll else None)
 
@@ -125,7 +126,17 @@ class _EarthSpecificBlock(nn.Module):
                                      precision=self.attention_precision)
             x = x + self.attn.proj(a)
             return x + self.mlp(self.norm2(x)), None
-        # residual adds as GEMM accumulation in place on x, Linear biases deferred into `pend` (ops.residual_block_tail)
+        if self.linear_form == "bf16x6" and ops.attention_block_linears_supported(self.dim, self.mlp.fc1.out_features):
+            # the four Linears as dlwp_linear_f32 (fp32-accurate GEMM on the bf16 pipe), bias / GELU / residual adds in their
+            # epilogues, in place on x
+            if pend is not None:
+                x.add_(pend)
+            qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), self.attn.qkv)
+            a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec,
+                                     precision=self.attention_precision)
+            return ops.attention_block_tail(x, a, self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2), None
+        # rocBLAS form: residual adds as GEMM accumulation in place on x, Linear biases deferred into `pend`
+        # (ops.residual_block_tail)
         qkv = self.attn.qkv(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre_bias=pend))
         a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec,
                                  precision=self.attention_precision)
@@ -154,6 +165,7 @@ class _DownSample(nn.Module):
         super().__init__()
         self.linear = nn.Linear(in_dim * 4, in_dim * 2, bias=False)
         self.norm = ops.HipLayerNorm(4 * in_dim)
+        self.linear_form = "bf16x6"
         self.input_resolution, self.output_resolution = tuple(input_resolution), tuple(output_resolution)
 
     def forward(self, x):
@@ -164,7 +176,7 @@ class _DownSample(nn.Module):
         x = x.reshape(b, pl, lat, lon, c)
         x = F.pad(x, (0, 0, wp // 2, wp - wp // 2, hp // 2, hp - hp // 2))
         x = x.reshape(b, pl, olat, 2, olon, 2, c).permute(0, 1, 2, 4, 3, 5, 6).reshape(b, pl * olat * olon, 4 * c)
-        return self.linear(self.norm(x))
+        return ops.linear_as(self.linear_form, self.norm(x), self.linear)
 
 
 class _UpSample(nn.Module):
@@ -173,18 +185,19 @@ class _UpSample(nn.Module):
         self.linear1 = nn.Linear(in_dim, out_dim * 4, bias=False)
         self.linear2 = nn.Linear(out_dim, out_dim, bias=False)
         self.norm = ops.HipLayerNorm(out_dim)
+        self.linear_form = "bf16x6"
         self.input_resolution, self.output_resolution = tuple(input_resolution), tuple(output_resolution)
 
     def forward(self, x):
         b, n, c = x.shape
         pl, lat, lon = self.input_resolution
         _, olat, olon = self.output_resolution
-        x = self.linear1(x)
+        x = ops.linear_as(self.linear_form, x, self.linear1)
         x = x.reshape(b, pl, lat, lon, 2, 2, c // 2).permute(0, 1, 2, 4, 3, 5, 6).reshape(b, pl, lat * 2, lon * 2, -1)
         ph, pw = lat * 2 - olat, lon * 2 - olon
         x = x[:, :pl, ph // 2: 2 * lat - (ph - ph // 2), pw // 2: 2 * lon - (pw - pw // 2), :]
         x = x.reshape(b, -1, x.shape[-1])
-        return self.linear2(self.norm(x))
+        return ops.linear_as(self.linear_form, self.norm(x), self.linear2)
 
 
 class _PatchEmbed2D(nn.Module):
@@ -245,6 +258,16 @@ class PanguWeather(HipBackbone):
         for m in self.modules():
             if hasattr(m, "attention_precision"):
                 m.attention_precision = precision
+        return self
+
+    def set_linear_form(self, form: str):
+        """"bf16x6" (default): the blocks' Linears run dlwp_linear_f32 (fp32-accurate on the bf16 matrix pipe, fused epilogues);
+        "rocblas": torch's fp32 GEMMs.  Each is the other's cross-check.  Per-module state."""
+        if form not in ("bf16x6", "rocblas"):
+            raise _lib.DlwpError(f"unknown linear form {form!r}")
+        for m in self.modules():
+            if hasattr(m, "linear_form"):
+                m.linear_form = form
         return self
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:

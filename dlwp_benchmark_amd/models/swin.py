@@ -64,6 +64,7 @@ class _Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self.attention_precision = "fp32"
+        self.linear_form = "bf16x6"      # "bf16x6": dlwp_linear_f32; "rocblas": fp32 rocBLAS GEMMs (cross-check / A-B timing)
 
     def forward(self, x, h, w, pend=None):
         """x holds (true x - pend); returns (x, pend) in the same convention (pend None = nothing pending)."""
@@ -89,7 +90,17 @@ class _Block(nn.Module):
                                      precision=self.attention_precision)
             x = x + self.attn.proj(a)
             return x + self.mlp(self.norm2(x)), None
-        # residual adds as GEMM accumulation in place on x, Linear biases deferred into `pend` (ops.residual_block_tail)
+        if self.linear_form == "bf16x6" and ops.attention_block_linears_supported(self.dim, self.mlp.fc1.out_features):
+            # the four Linears as dlwp_linear_f32 (fp32-accurate GEMM on the bf16 pipe), bias / GELU / residual adds in their
+            # epilogues, in place on x
+            if pend is not None:
+                x.add_(pend)
+            qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), self.attn.qkv)
+            a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.relative_position_bias_table, spec,
+                                     precision=self.attention_precision)
+            return ops.attention_block_tail(x, a, self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2), None
+        # rocBLAS form: residual adds as GEMM accumulation in place on x, Linear biases deferred into `pend`
+        # (ops.residual_block_tail)
         qkv = self.attn.qkv(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre_bias=pend))
         a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.relative_position_bias_table, spec,
                                  precision=self.attention_precision)
@@ -102,6 +113,7 @@ class _PatchMerging(nn.Module):
         super().__init__()
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
         self.norm = norm_layer(4 * dim)
+        self.linear_form = "bf16x6"
 
     def forward(self, x, h, w):
         b, l, c = x.shape
@@ -110,7 +122,7 @@ class _PatchMerging(nn.Module):
                                  "swin_transformer.py:293-296)")
         x = x.view(b, h, w, c)
         x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).view(b, -1, 4 * c)
-        return self.reduction(self.norm(x))
+        return ops.linear_as(self.linear_form, self.norm(x), self.reduction)
 
 
 class _BasicLayer(nn.Module):
@@ -208,6 +220,16 @@ class SwinTransformer(HipBackbone):
         for m in self.modules():
             if hasattr(m, "attention_precision"):
                 m.attention_precision = precision
+        return self
+
+    def set_linear_form(self, form: str):
+        """"bf16x6" (default): the blocks' Linears run dlwp_linear_f32 (fp32-accurate on the bf16 matrix pipe, fused epilogues);
+        "rocblas": torch's fp32 GEMMs.  Each is the other's cross-check.  Per-module state."""
+        if form not in ("bf16x6", "rocblas"):
+            raise _lib.DlwpError(f"unknown linear form {form!r}")
+        for m in self.modules():
+            if hasattr(m, "linear_form"):
+                m.linear_form = form
         return self
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:

@@ -2,6 +2,7 @@
 Every wrapper takes CUDA tensors, passes raw pointers + the current HIP stream, and raises
 `DlwpError` on a non-zero status.  No wrapper has a CPU path."""
 import ctypes
+import functools
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -649,6 +650,105 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
                                                   y.data_ptr(), rows, c, float(eps), _lib.stream_ptr()),
                    "dlwp_layernorm_prebias_f32")
     return y
+
+
+@functools.lru_cache(maxsize=None)
+def linear_supported(in_features: int, out_features: int) -> bool:
+    """True when dlwp_linear_f32 handles this Linear shape (in % 32 == 0, out % 4 == 0)."""
+    return int(_lib.load().dlwp_linear_packed_bytes(int(out_features), int(in_features))) > 0
+
+
+class LinearWeights:
+    """A Linear weight [out, in] split into the three bf16 images dlwp_linear_f32 reads, re-split on the device whenever
+    the parameter has been written to (optimizer step, load_state_dict, .to()).  Derived data: not in any state dict."""
+
+    def __init__(self):
+        self._key = None
+        self._buf = None
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        key = (weight.data_ptr(), weight._version, str(weight.device))
+        if key != self._key:
+            n, k = weight.shape
+            lib = _lib.load()
+            nbytes = int(lib.dlwp_linear_packed_bytes(n, k))
+            if nbytes == 0:
+                raise _lib.DlwpError(f"linear: unsupported shape out={n} in={k} (need in % 32 == 0 and out % 4 == 0)")
+            buf = torch.empty(nbytes // 4, dtype=torch.int32, device=weight.device)
+            with torch.cuda.device(weight.device):
+                _lib.check(lib.dlwp_linear_pack_f32(weight.detach().contiguous().data_ptr(), n, k, buf.data_ptr(),
+                                                    _lib.stream_ptr()), "dlwp_linear_pack_f32")
+            self._key, self._buf = key, buf
+        return self._buf
+
+
+def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ m.weight.T + m.bias) + resid over the last dimension in one launch (dlwp_linear_f32: fp32-accurate GEMM on the
+    bf16 matrix pipe; act 0 none / 1 exact GELU).  `out` may be `resid` (in-place residual add).  With gradients wanted the
+    torch operators run instead (training.py's convention)."""
+    from . import training as _T
+    if _T.wants_grad(x, m.weight, m.bias, resid):
+        y = torch.nn.functional.linear(x, m.weight, m.bias)
+        if act == 1:
+            y = torch.nn.functional.gelu(y)
+        elif act != 0:
+            raise _lib.DlwpError(f"linear: activation {act} not supported")
+        return y if resid is None else y + resid
+    _lib.require_cuda_tensor(x, "x")
+    if act not in (0, 1):
+        raise _lib.DlwpError(f"linear: activation {act} not supported")
+    x = x.contiguous()
+    k, n = m.in_features, m.out_features
+    if x.shape[-1] != k:
+        raise _lib.DlwpError(f"linear: input width {x.shape[-1]} does not match in_features {k}")
+    cache = m.__dict__.get("_dlwp_packed")
+    if cache is None:
+        cache = LinearWeights()
+        m.__dict__["_dlwp_packed"] = cache       # plain attribute: neither parameter nor buffer, not in the state dict
+    packed = cache.get(m.weight)
+    shape = (*x.shape[:-1], n)
+    if resid is not None:
+        _lib.require_cuda_tensor(resid, "resid")
+        if tuple(resid.shape) != shape or not resid.is_contiguous():
+            raise _lib.DlwpError("linear: resid must be contiguous and shaped like the output")
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape or not out.is_contiguous():
+        raise _lib.DlwpError("linear: out must be contiguous and shaped like the output")
+    if out.data_ptr() == x.data_ptr():
+        raise _lib.DlwpError("linear: out must not alias x")
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dlwp_linear_f32(x.data_ptr(), packed.data_ptr(),
+                                       m.bias.contiguous().data_ptr() if m.bias is not None else None,
+                                       resid.data_ptr() if resid is not None else None, out.data_ptr(),
+                                       x.numel() // k, k, n, int(act), _lib.stream_ptr()), "dlwp_linear_f32")
+    return out
+
+
+def linear_as(form: str, x: torch.Tensor, m: torch.nn.Linear) -> torch.Tensor:
+    """m(x) through dlwp_linear_f32 when form == "bf16x6" and the shape is covered, else the module itself (rocBLAS)."""
+    if form == "bf16x6" and x.is_cuda and linear_supported(m.in_features, m.out_features):
+        return linear(x, m)
+    return m(x)
+
+
+def attention_block_linears_supported(dim: int, hidden: int) -> bool:
+    return linear_supported(dim, 3 * dim) and linear_supported(dim, dim) and linear_supported(dim, hidden) \
+        and linear_supported(hidden, dim)
+
+
+def attention_block_tail(x: torch.Tensor, attn_out: torch.Tensor, proj: torch.nn.Linear, norm2: torch.nn.LayerNorm,
+                         fc1: torch.nn.Linear, fc2: torch.nn.Linear) -> torch.Tensor:
+    """`x = x + proj(attn_out); x = x + fc2(gelu(fc1(norm2(x))))` of a Swin / Pangu block (swin_transformer.py:254-262,
+    panguweather.py:318-322), IN PLACE on x: three dlwp_linear_f32 launches (bias, GELU and both residual adds in the GEMM
+    epilogues) and one LayerNorm."""
+    linear(attn_out, proj, resid=x, out=x)
+    n2 = layer_norm(x, norm2.weight, norm2.bias, norm2.eps)
+    hid = linear(n2, fc1, act=1)
+    linear(hid, fc2, resid=x, out=x)
+    return x
 
 
 def residual_block_tail(x: torch.Tensor, pend: Optional[torch.Tensor], attn_out: torch.Tensor, proj: torch.nn.Linear,

@@ -303,6 +303,21 @@ int32_t dlwp_conv3x3_ex_f32(const float* x0_dev, int32_t c0, const float* x1_dev
                             int32_t width, int32_t cout, int32_t pre_act, int32_t act, const int32_t* ring_table, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * fp32 Linear layers on the bf16 matrix pipe with the block's pointwise work fused (csrc/linear.hip): the qkv / proj /
+ * fc1 / fc2 Linears, GELU and residual adds of the Swin and Pangu blocks (swin_transformer.py:21-39, :107-120, :254-262;
+ * panguweather.py:176-211, :318-322).
+ *   out[m][n] = act(sum_k x[m][k] W[n][k] + bias[n]) + resid[m][n],  act: 0 none, 1 exact-erf GELU
+ * fp32 tensors, fp32-GEMM accuracy (exact three-way bf16 splits of both operands, six cross products, fp32 accumulation).
+ * weight_dev [out, in] (nn.Linear layout) is split once by dlwp_linear_pack_f32 into `packed_dev`
+ * (dlwp_linear_packed_bytes bytes, caller-owned; 0 = unsupported: in % 32 != 0 or out % 4 != 0); bias / resid may be NULL,
+ * resid may alias out (in-place residual).
+ * ------------------------------------------------------------------------------------------ */
+size_t dlwp_linear_packed_bytes(int32_t out_features, int32_t in_features);
+int32_t dlwp_linear_pack_f32(const float* weight_dev, int32_t out_features, int32_t in_features, void* packed_dev, void* stream);
+int32_t dlwp_linear_f32(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                        float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * The remaining U-Net / ModernUNet operators (csrc/conv2.hip), NCHW fp32, activations as above.
  *   dlwp_groupnorm_act_f32     y = act(GroupNorm(groups)(x)): unet.py:739 (+ GELU :761), :887-888; gamma / beta [C] or NULL
  *   dlwp_conv2d_f32            zero-padded Conv2d k x k, stride s: unet.py:583 (3x3 s2 p1), :584 / :879 / :450 (1x1);

@@ -1,0 +1,127 @@
+"""Op-level parity of dlwp_linear_f32 (csrc/linear.hip: fp32 Linear on the bf16 matrix pipe with bias / GELU / residual fused)
+against torch.nn.functional.linear evaluated in float64 -- the operator the Swin / Pangu blocks call for qkv, proj, fc1 and
+fc2 (swin_transformer.py:21-39, :107-120; panguweather.py:176-211).  Tolerance: fp32 GEMM accuracy (1e-6 relative L2; a plain
+fp32 rocBLAS GEMM lands at 2e-7 .. 5e-7 on the same inputs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _linear(k, n, bias, seed):
+    torch.manual_seed(seed)
+    m = torch.nn.Linear(k, n, bias=bias)
+    with torch.no_grad():
+        m.weight.mul_(3.0)
+    return m.to(DEV)
+
+
+# rows: a tile tail (M % 128 != 0), fewer rows than one tile, many tiles (all 8 XCD slots + tail group);
+# widths: the C3 / C5 widths, the BN = 64 path (192, 576), N tail inside a tile (N = 100), K = 32 (one k-step)
+@pytest.mark.parametrize("rows,k,n,bias,act,resid", [
+    (1000, 96, 288, True, 0, False), (77, 96, 96, True, 0, True), (4096, 96, 384, True, 1, False),
+    (4096, 384, 96, True, 0, True), (2051, 192, 576, True, 0, False), (513, 768, 192, True, 0, True),
+    (300, 32, 100, False, 1, True), (129, 64, 4, True, 0, False), (9000, 384, 1536, True, 1, False),
+    (1, 1536, 384, False, 0, True)])
+def test_linear_matches_float64(rows, k, n, bias, act, resid):
+    from dlwp_benchmark_amd import ops
+
+    m = _linear(k, n, bias, seed=rows + k)
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, k, generator=g) * 2.0 + 0.3).to(DEV)
+    r = torch.randn(rows, n, generator=g).to(DEV) if resid else None
+    with torch.no_grad():
+        got = ops.linear(x, m, act=act, resid=r)
+        want = F.linear(x.double(), m.weight.double(), m.bias.double() if bias else None)
+        if act:
+            want = F.gelu(want)
+        if resid:
+            want = want + r.double()
+    assert got.shape == want.shape
+    assert rel_l2(got, want) <= 1e-6
+    assert (got.double() - want).abs().max() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_linear_in_place_residual_and_leading_dims():
+    from dlwp_benchmark_amd import ops
+
+    m = _linear(96, 96, True, seed=5)
+    x = torch.randn(2, 150, 96, device=DEV)
+    acc = torch.randn(2, 150, 96, device=DEV)
+    with torch.no_grad():
+        want = F.linear(x.double(), m.weight.double(), m.bias.double()) + acc.double()
+        out = ops.linear(x, m, resid=acc, out=acc)
+    assert out.data_ptr() == acc.data_ptr() and out.shape == (2, 150, 96)
+    assert rel_l2(out, want) <= 1e-6
+
+
+def test_linear_repacks_after_weight_update():
+    from dlwp_benchmark_amd import ops
+
+    m = _linear(64, 64, True, seed=6)
+    x = torch.randn(200, 64, device=DEV)
+    with torch.no_grad():
+        first = ops.linear(x, m).clone()
+        m.weight.mul_(-2.0)                   # in-place write bumps the version: the packed images must follow
+        second = ops.linear(x, m)
+        want = F.linear(x.double(), m.weight.double(), m.bias.double())
+    assert rel_l2(second, want) <= 1e-6
+    assert not torch.allclose(first, second)
+
+
+def test_linear_rejects_unsupported_shapes_loudly():
+    from dlwp_benchmark_amd import lib, ops
+
+    assert not ops.linear_supported(48, 96) and not ops.linear_supported(64, 6)
+    m = _linear(48, 96, True, seed=7)
+    with torch.no_grad(), pytest.raises(lib.DlwpError):
+        ops.linear(torch.randn(10, 48, device=DEV), m)
+    m = _linear(64, 64, True, seed=8)
+    with torch.no_grad(), pytest.raises(lib.DlwpError):
+        ops.linear(torch.randn(10, 32, device=DEV), m)
+
+
+def test_linear_is_differentiable_through_torch_ops():
+    from dlwp_benchmark_amd import ops
+
+    m = _linear(64, 128, True, seed=9)
+    x = torch.randn(50, 64, device=DEV, requires_grad=True)
+    y = ops.linear(x, m, act=1)
+    y.square().sum().backward()
+    ref = F.gelu(F.linear(x.detach().double(), m.weight.double(), m.bias.double()))
+    assert rel_l2(y.detach(), ref) <= 1e-6 and x.grad is not None and m.weight.grad is not None
+
+
+@pytest.mark.parametrize("tag", ["swin_e32_32x64", "swin_c3_full", "pangu_c5_full"])
+def test_block_linear_forms_hold_the_reference_bound(tag):
+    """The two forms of the blocks' Linears (dlwp_linear_f32 / rocBLAS) against the REAL reference's trajectory
+    (tests/golden/model_*.npz): both must hold the 1e-5 per-step bound, and agree with each other to fp32 rounding."""
+    import json
+
+    import dlwp_benchmark_amd.models as M
+    from dlwp_benchmark_amd.weights import fill_by_spec
+    from helpers import load_golden, per_step_rel_l2
+    from oracle.make_golden import MODEL_CASES, model_inputs
+
+    family, cfg, (batch, frames), gain = MODEL_CASES[tag]
+    name = {"swin": "SwinTransformer", "pangu": "PanguWeather"}[family]
+    g = load_golden(f"model_{tag}")
+    sd, _ = fill_by_spec(json.loads(str(g["param_spec"])), gain=gain)
+    model = getattr(M, name)(**cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV).eval()
+    constants, prescribed, prognostic = model_inputs(tag, cfg, batch, frames)
+    dev = lambda t: t.to(DEV) if t is not None else None
+    want = torch.from_numpy(g["y"])
+    outs = {}
+    for form in ("bf16x6", "rocblas"):
+        model.set_linear_form(form)
+        outs[form] = model(constants=dev(constants), prescribed=dev(prescribed), prognostic=dev(prognostic)).clone()
+        torch.cuda.synchronize()
+        errs = per_step_rel_l2(outs[form], want)
+        assert max(errs) <= 1e-5, f"{tag} {form}: per-step rel L2 {['%.2e' % e for e in errs]}"
+    assert rel_l2(outs["bf16x6"], outs["rocblas"]) <= 5e-6
