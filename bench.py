@@ -192,7 +192,9 @@ def bench_other_configs(device, only=None, reps=2):
     for tag, (cls, cfg, batch, steps, (h, w), gold, gain) in other_config_table().items():
         if only and tag not in only:
             continue
-        variants = ["fp32"] + (["bf16"] if cls in ("SwinTransformer", "PanguWeather") else [])
+        # "bf16": bf16 window attention only; "bf16all": bf16 attention AND bf16 Linear operands (the autocast(bfloat16)
+        # analogue BASELINE configs[2] names); fp32 accumulation, LayerNorm and residual stream in all of them
+        variants = ["fp32"] + (["bf16", "bf16all"] if cls in ("SwinTransformer", "PanguWeather") else [])
         model = getattr(M, cls)(**cfg)
         sha = fill_state_dict(model, gain=gain)
         model = model.to(device).eval()
@@ -208,11 +210,14 @@ def bench_other_configs(device, only=None, reps=2):
             gz = np.load(gpath, allow_pickle=False)
             if str(gz["sha"]) == sha:
                 want = torch.from_numpy(gz["y"])
-        for prec in variants:
+        for variant in variants:
+            prec = "fp32" if variant == "fp32" else "bf16"
             if hasattr(model, "set_attention_precision"):
                 model.set_attention_precision(prec)
-            entry = {"workload": f"{cls} {h}x{w}, {cfg['prognostic_channels']} prognostic ch, {steps}-step rollout, "
-                                 f"{'bf16 window attention (fp32 elsewhere)' if prec == 'bf16' else 'fp32'}",
+                model.set_linear_form("bf16" if variant == "bf16all" else "bf16x6")
+            what = {"fp32": "fp32", "bf16": "bf16 window attention (fp32 elsewhere)",
+                    "bf16all": "bf16 window attention and bf16 Linear operands (fp32 accumulation, LayerNorm, residual stream)"}[variant]
+            entry = {"workload": f"{cls} {h}x{w}, {cfg['prognostic_channels']} prognostic ch, {steps}-step rollout, {what}",
                      "batch": batch, "rollout_steps": steps, "weights": "deterministic filler sha256:" + sha[:16]}
             out = model(constants=c, prescribed=p, prognostic=g)      # warm-up (plans, allocator)
             torch.cuda.synchronize()
@@ -251,7 +256,7 @@ def bench_other_configs(device, only=None, reps=2):
                                                         sorted(by_name.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}
             entry["share_outside_libdlwp_hip"] = max(0.0, 1.0 - covered / (dt * 1e3))   # rocBLAS / MIOpen / torch glue
             entry["roofline"] = _other_roofline(cls, cfg, batch, h, w, summ, prec)
-            res[tag if prec == "fp32" else tag + "_bf16attn"] = entry
+            res[tag + {"fp32": "", "bf16": "_bf16attn", "bf16all": "_bf16"}[variant]] = entry
         del model, out
         torch.cuda.empty_cache()
     return res

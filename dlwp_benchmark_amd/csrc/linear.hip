@@ -5,23 +5,38 @@
 // models/panguweather/panguweather.py:176-211, :318-322) which round 1 ran as fp32 rocBLAS GEMMs (51 % of the Pangu step)
 // plus separate GELU and add passes:
 //   out[m][n] = act( sum_k x[m][k] W[n][k] + bias[n] ) + resid[m][n]          (act: none | exact-erf GELU)
-// fp32 in, fp32 out, fp32-GEMM accuracy: every operand is split EXACTLY into three bf16 parts (x = h + m + l) and the six
-// significant cross products are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (common.hpp; measured as accurate as
-// a plain fp32 GEMM).  The bf16 pipe is 16x the fp32 matrix rate, so six passes still leave 2.6x -- and the fp32 vector
-// lanes stay free for the splits and the epilogue.
+// fp32 in, fp32 out.  NP = 3 (dlwp_linear_f32): fp32-GEMM accuracy -- every operand is split EXACTLY into three bf16 parts
+// (x = h + m + l) and the six significant cross products are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (common.hpp;
+// measured MORE accurate than rocBLAS' fp32 GEMM on the same inputs, tools/bench_linear.py).  The bf16 pipe is 16x the fp32
+// matrix rate, so six passes still leave 2.6x -- and the fp32 vector lanes stay free for the splits and the epilogue.
+// NP = 1 (dlwp_linear_bf16): bf16 operands (one product), fp32 accumulation -- what autocast(bfloat16) makes of nn.Linear.
 //
 // Weights are split ONCE (dlwp_linear_pack_f32: three bf16 images [N][K]); activations are split while their tile is
-// staged into LDS.  Tile: BM = 128 rows of x, BN = 128 or 64 rows of W, BK = 32; 256 threads = 2 x 2 waves, a wave owns
-// 64 x BN/2 outputs = 4 x (BN/32) MFMA tiles.  The MFMA takes W as its A operand and x as its B operand, so a lane ends
-// up with 4 CONSECUTIVE output columns n of one row m: bias / residual / store are 16-byte accesses.  One LDS buffer,
-// next k-step's global loads in flight in registers during the current step's MFMAs.
+// staged into LDS.  Tile: BM = 128 rows of x, BN = 128 or 96 rows of W, BK = 32; 256 threads = 2 x 2 waves, a wave owns
+// 64 x BN/2 outputs = 4 x (BN/32) MFMA tiles; 72 KB (60 KB) of LDS: two workgroups per CU.  The MFMA takes W as its A operand
+// and x as its B operand, so a lane ends up with 4 CONSECUTIVE output columns n of one row m: bias / residual / store
+// are 16-byte accesses.
+//
+// Structure (what each piece bought is in DESIGN.md section 7.5):
+//   * persistent workgroups walk a list of output tiles as ONE flattened sequence of k-steps: the loads of the first
+//     k-steps of the next tile are issued during the last k-steps of the current one, so short-K Linears (K = 96: three
+//     k-steps) have no prologue bubble per tile.  XCD x (= blockIdx % 8) owns the 128-row slabs x, x + 8, ... of the
+//     activation; its workgroups walk (slab, n-tile) pairs n-tile fastest, so a slab is fetched into that XCD's L2 once;
+//   * W tiles (already bf16) go global -> LDS by LDS-DMA into two buffers, one k-step ahead; x tiles (fp32) come through
+//     registers: x(t+1) is split at the start of step t behind a barrier (every wave holds its x fragments of step t in
+//     registers first, so ONE x buffer suffices) and x(t+2) is issued into the same registers right behind the split;
+//   * every load in the loop is inline asm with hand-counted s_waitcnt vmcnt(N), tied to the registers it releases:
+//     hipcc cannot count loads whose use is an iteration away and drains the queue (vmcnt(0)) instead -- the same reason
+//     the output stores are asm and every compiler-visible load of the epilogue is consumed on every path;
+//   * LDS rows are 64 bytes (32 bf16), unpadded, with the 16-byte chunks XOR-swizzled by f(row) = (4 - (row & 15) / 4) & 3:
+//     the ds_read_b128 operand reads (lane groups {0-3, 12-15, 20-27}, ...) are conflict free (SQ_LDS_BANK_CONFLICT = 0).
 #include "common.hpp"
+#include <type_traits>
 
 namespace dlwp {
 namespace lin {
 
 constexpr int BM = 128, BK = 32;
-constexpr int LDT = BK + 16;   // bf16 elements per LDS row (96 bytes: conflict-free for the b128 operand reads, see window_attn2.hip)
 
 struct Params {
   const float* x;              // [M][K]
@@ -33,29 +48,126 @@ struct Params {
   int N, K, act;
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) { return act == 1 ? gelu_erf(v) : v; }
+// Output stores as inline asm: hipcc guards the reuse of a store's data registers with s_waitcnt vmcnt -- and knowing
+// nothing of the asm prefetches queued behind the stores it makes that vmcnt(0), draining the pipeline once per tile.
+// The hardware reads the data at issue; it only asks for wait states before a write to the registers of a wide store
+// (the trailing s_nop 1, checked by tools/asm_hazard_check.py rule C).
+__device__ __forceinline__ void store4(float* dst, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+}
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void linear_bf16x6_kernel(const Params p) {
+__device__ __forceinline__ int swz(int row) { return (4 - ((row & 15) >> 2)) & 3; }
+
+struct Cursor {          // one (tile, k-step) position of this workgroup's flattened step sequence
+  int slab, nt, ks, left;    // slab index inside the XCD, n-tile, k-step, tiles after this one
+};
+
+template <int BN, int NP>
+__global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   constexpr int TN = BN / 32;                        // 16-row W tiles per wave (wave tile: 64 m x BN/2 n)
-  extern __shared__ __align__(16) unsigned short smem_u16[];
-  typedef unsigned short (*XT)[BM][LDT];
-  typedef unsigned short (*WT)[BN][LDT];
-  XT s_x = reinterpret_cast<XT>(smem_u16);                              // [3][BM][LDT]
-  WT s_w = reinterpret_cast<WT>(smem_u16 + 3 * BM * LDT);               // [3][BN][LDT]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int XBYTES = NP * 8192;                  // x tile: NP parts x 128 rows x 64 bytes
+  constexpr int WPART = BN * 64, WSTAGE = NP * WPART;
+  constexpr int CH = NP * BN * 4;                    // 16-byte chunks per W stage
+  constexpr int PIECES = CH / 64;                    // 1 KiB LDS-DMA pieces (16 rows x 64 bytes) per W stage
+  constexpr int G = (PIECES + 3) / 4;                // pieces per wave and k-step
+  extern __shared__ __align__(1024) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
-  const int wm = wave & 1, wn = wave >> 1;           // wave grid 2 (m) x 2 (n)
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // this workgroup's tiles: XCD x (= blockIdx % 8) owns the 128-row slabs x, x + 8, ...; its workgroups walk the
+  // (slab, n-tile) pairs n-tile fastest, so the workgroups that run together on an XCD share slabs of x in its L2
   const int tiles_n = (p.N + BN - 1) / BN;
-  // the tiles_n workgroups that share one 128-row slab of x run on ONE XCD (blocks are dealt round-robin over the 8 XCDs
-  // by linear id): the slab is fetched into that XCD's L2 once
-  const int xcd = blockIdx.x & 7;
-  const long long rloc = blockIdx.x >> 3;
-  const long long tile_m = (rloc / tiles_n) * 8 + xcd;
-  const int tile_n = (int)(rloc % tiles_n);
-  const long long m0 = tile_m * BM;
-  if (m0 >= p.M) return;
-  const int n0 = tile_n * BN;
+  const long long tiles_m = (p.M + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int slabs = tiles_m > xcd ? (int)((tiles_m - xcd + 7) / 8) : 0;
+  const int ntile = slabs * tiles_n;                 // (host: fits an int)
+  if (ntile <= li) return;
+  const int my_tiles = (ntile - li + per_xcd - 1) / per_xcd;
+  const int nk = p.K / BK;
+  const long long total = (long long)my_tiles * nk;
+  const int dq = per_xcd / tiles_n, dr = per_xcd % tiles_n;      // one stride of the tile sequence in (slab, n-tile) steps
+
+  auto advance = [&](Cursor& c) -> bool {            // true when the cursor moved to another tile
+    if (++c.ks < nk) return false;
+    c.ks = 0;
+    if (c.left == 0) return false;                   // past the end: stay on the last tile (re-loaded, results unused)
+    --c.left;
+    c.slab += dq;
+    c.nt += dr;
+    if (c.nt >= tiles_n) { c.nt -= tiles_n; ++c.slab; }
+    return true;
+  };
+  auto row0 = [&](const Cursor& c) -> long long { return ((long long)c.slab * 8 + xcd) * BM; };
+
+  // ---- x stream: 128 rows x 32 floats per k-step, 4 float4 per thread.  Loads are `global_load_dwordx4 v, voffset, s[base]`:
+  // a scalar tile base (advanced by the cursor) plus a 32-bit per-thread offset, half the address registers of flat pointers.
+  unsigned xoff[4];
+  auto x_rows = [&](const Cursor& c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + q * 256, r = i >> 3, c4 = i & 7;
+      const long long left = p.M - 1 - row0(c);                   // rows past M: clamped to the last row, never stored
+      const int rr = r < left ? r : (int)left;
+      xoff[q] = ((unsigned)rr * (unsigned)p.K + 4u * c4) * 4u;
+    }
+  };
+  auto x_issue = [&](f32x4 (&dst)[4], const Cursor& c) {
+    const float* base = p.x + row0(c) * p.K + c.ks * BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[q]) : "v"(xoff[q]), "s"(base));
+  };
+  // ---- W stream: NP x BN rows x 64 bytes per k-step = PIECES 1 KiB pieces (16 rows x 64 bytes) moved global -> LDS by
+  // global_load_lds_dwordx4: no registers, no ds_write.  Wave w moves pieces w, w + 4, ... (a wave whose last index
+  // falls past PIECES repeats its previous piece: every wave issues exactly G, so one vmcnt constant serves all).
+  // M0 = LDS base of the piece; lane l lands at + 16 l = row l / 4, position l % 4, which must hold the k-chunk
+  // (l % 4) ^ f(row): the swizzle is applied to the SOURCE address.
+  // [Register staging of W (global_load_dwordx4 + ds_write_b128, 24 more VGPRs) was measured on the same structure: equal
+  // within 4 %, slower on the K >= 384 shapes.  The pieces are slow to ISSUE -- 6 per wave took 570-1700 cycles, the
+  // LDS-DMA path moves ~13 B/clk/CU -- but the other workgroup of the CU computes meanwhile.]
+  unsigned woff[G], wdst[G];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto w_rows = [&](const Cursor& c) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      int pc = wave + 4 * i;
+      if (pc >= PIECES) pc -= 4;
+      const int part = pc / (BN / 16), rb = pc % (BN / 16), r = lane >> 2, pos = lane & 3;
+      const int nn = c.nt * BN + 16 * rb + r;
+      const int n = nn < p.N ? nn : p.N - 1;                       // rows past N: clamped, never stored
+      woff[i] = ((unsigned)part * (unsigned)p.wpart + (unsigned)n * (unsigned)p.K + 8u * (pos ^ swz(r))) * 2u;
+      wdst[i] = lds0 + XBYTES + pc * 1024;
+    }
+  };
+  auto w_dma = [&](int buf, const Cursor& c) {
+    const unsigned short* base = p.w + c.ks * BK;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(wdst[i] + buf * WSTAGE);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(woff[i]), "s"(base), "s"(dst) : "memory");
+    }
+  };
+  // ---- split a register set into the x tile
+  auto x_store = [&](const f32x4 (&src)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + q * 256, r = i >> 3, c4 = i & 7;
+      unsigned char* d = smem + r * 64 + (((c4 >> 1) ^ swz(r)) << 4) + ((c4 & 1) << 3);
+      if constexpr (NP == 3) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(src[q][0], src[q][1], h0, m0_, l0);
+        split3_pair(src[q][2], src[q][3], h1, m1, l1);
+        *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
+        *reinterpret_cast<uint2*>(d + 8192) = uint2{m0_, m1};
+        *reinterpret_cast<uint2*>(d + 16384) = uint2{l0, l1};
+      } else {
+        *reinterpret_cast<uint2*>(d) = uint2{cvt_pk_bf16(src[q][0], src[q][1]), cvt_pk_bf16(src[q][2], src[q][3])};
+      }
+    }
+  };
 
   f32x4 acc[4][TN];
 #pragma unroll
@@ -63,100 +175,136 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x6_kernel(const Params p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging: x tile 128 rows x 32 floats = 1024 float4 -> 4 per thread; W tiles 3 x BN rows x 64 bytes = 12 BN 16-byte chunks
-  constexpr int WCH = 3 * BN * 4 / 256;              // 16-byte chunks per thread (BN = 128: 6, BN = 64: 3)
-  float4 px[4];
-  u32x4 pw[WCH];
-  // rows past M / N are CLAMPED to the last valid row (no branches, no zero fill): their products land in accumulators
-  // the epilogue never stores
-  constexpr int WPP = BN * 4 / 256;                  // 16-byte chunks per thread per W part (BN = 128: 2, BN = 64: 1)
-  const float* xsrc[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = tid + q * 256, r = i >> 3, c4 = i & 7;
-    const long long m = m0 + r < p.M ? m0 + r : p.M - 1;
-    xsrc[q] = p.x + m * p.K + 4 * c4;
-  }
-  const unsigned short* wsrc[WPP];
-#pragma unroll
-  for (int q = 0; q < WPP; ++q) {
-    const int rem = tid + q * 256, r = rem >> 2, c8 = rem & 3;
-    const int n = n0 + r < p.N ? n0 + r : p.N - 1;
-    wsrc[q] = p.w + (long long)n * p.K + 8 * c8;
-  }
-  const long long wpart = p.wpart;
-  auto load = [&](int k0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) px[q] = *reinterpret_cast<const float4*>(xsrc[q] + k0);
-#pragma unroll
-    for (int q = 0; q < WCH; ++q) pw[q] = *reinterpret_cast<const u32x4*>(wsrc[q % WPP] + (q / WPP) * wpart + k0);
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = tid + q * 256, r = i >> 3, c4 = i & 7;
-      unsigned h0, m0_, l0, h1, m1, l1;
-      split3_pair(px[q].x, px[q].y, h0, m0_, l0);
-      split3_pair(px[q].z, px[q].w, h1, m1, l1);
-      *reinterpret_cast<uint2*>(&s_x[0][r][4 * c4]) = uint2{h0, h1};
-      *reinterpret_cast<uint2*>(&s_x[1][r][4 * c4]) = uint2{m0_, m1};
-      *reinterpret_cast<uint2*>(&s_x[2][r][4 * c4]) = uint2{l0, l1};
-    }
-#pragma unroll
-    for (int q = 0; q < WCH; ++q) {
-      const int rem = tid + (q % WPP) * 256, r = rem >> 2, c8 = rem & 3;
-      *reinterpret_cast<u32x4*>(&s_w[q / WPP][r][8 * c8]) = pw[q];
-    }
-  };
+  Cursor cc, cw, cx;        // compute position, W load position (one step ahead), x load position (two steps ahead)
+  cc.slab = li / tiles_n; cc.nt = li % tiles_n; cc.ks = 0; cc.left = my_tiles - 1;
+  cw = cc; cx = cc;
+  f32x4 px[4];
+  // prologue: x(0) split into the x tile, W(0) into buffer 0, x(1) on its way
+  x_rows(cx);
+  w_rows(cw);
+  x_issue(px, cx);
+  w_dma(0, cw);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]), "+v"(px[3]));
+  x_store(px);
+  if (advance(cx)) x_rows(cx);
+  x_issue(px, cx);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 
-  const int nk = p.K / BK;
-  load(0);
-  for (int ks = 0; ks < nk; ++ks) {
-    __syncthreads();                 // every wave is done reading the previous step's tiles
-    stage();
-    if (ks + 1 < nk) load((ks + 1) * BK);
-    __syncthreads();
-    u32x4 xb[4][3];
+  const unsigned char* xfrag = smem + (wm * 64 + j) * 64 + ((g ^ swz(j)) << 4);
+  const unsigned char* wfrag = smem + XBYTES + (wn * (BN / 2) + j) * 64 + ((g ^ swz(j)) << 4);
+
+  // epilogue: lane (j, g) holds out[m = m0 + wm 64 + 16 a + j][n = n0 + wn BN/2 + 16 b + 4 g + 0..3].  Two copies (with /
+  // without a residual operand): one body with `resid ? load : 0` made hipcc guard the zero-initialised registers of the
+  // other path with s_waitcnt vmcnt(0) -- a full drain of the stores just issued, once per tile.
+  auto epilogue = [&](auto has_resid) __attribute__((always_inline)) {
+    constexpr bool RES = decltype(has_resid)::value;
+    const long long mbase = row0(cc) + wm * 64 + j;
+    const int nbase = cc.nt * BN + wn * (BN / 2) + 4 * g;
+    // bias and ALL residual rows of the tile are requested together, from clamped addresses, and awaited once (one
+    // dependent load per bounds branch made hipcc drain the whole load queue, prefetches included, at every one of them;
+    // one batch per pair of row tiles paid the HBM latency twice per tile)
+    f32x4 bv[TN], rs[4][TN];
+    int ncl[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) ncl[b] = nbase + 16 * b < p.N ? nbase + 16 * b : p.N - 4;     // N % 4 == 0: a lane's 4 columns are all in or all out
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bv[b] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncl[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RES) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const long long m = mbase + 16 * a < p.M ? mbase + 16 * a : p.M - 1;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) rs[a][b] = *reinterpret_cast<const f32x4*>(p.resid + m * p.N + ncl[b]);
+      }
+    }
+    // every compiler-visible load is CONSUMED here, on every path: hipcc sinks `u += rs` into the bounds branch of the
+    // store, and a load still pending on the skip path costs an s_waitcnt vmcnt(0) at the first reuse of its register --
+    // the operand reads at the top of the next k-step, right behind the freshly issued prefetches
+#pragma unroll
+    for (int b = 0; b < TN; ++b) asm volatile("" : "+v"(bv[b]));
+    if constexpr (RES) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) asm volatile("" : "+v"(rs[a][b]));
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a += 2) {
+      const long long m_u = mbase + 16 * a, m_v = m_u + 16;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        f32x4 u = acc[a][b] + bv[b], v = acc[a + 1][b] + bv[b];
+        if (p.act) gelu_erf8_fma(u, v);
+        if constexpr (RES) {
+          u += rs[a][b];
+          v += rs[a + 1][b];
+        }
+        const int n = nbase + 16 * b;
+        if (n < p.N) {
+          if (m_u < p.M) store4(p.out + m_u * p.N + n, u);
+          if (m_v < p.M) store4(p.out + m_v * p.N + n, v);
+        }
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int part = 0; part < 3; ++part)
-        xb[a][part] = *reinterpret_cast<const u32x4*>(&s_x[part][wm * 64 + 16 * a + j][8 * g]);
-    // six cross products, smallest first: (A part, B part) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); A = W, B = x
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      u32x4 wa[3];
-#pragma unroll
-      for (int part = 0; part < 3; ++part)
-        wa[part] = *reinterpret_cast<const u32x4*>(&s_w[part][wn * (BN / 2) + 16 * b + j][8 * g]);
-#pragma unroll
-      for (int term = 0; term < 6; ++term)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_bf16(wa[PA[term]], xb[a][PB[term]], acc[a][b]);
-    }
-  }
+      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
 
-  // epilogue: lane (j, g) holds out[m = m0 + wm 64 + 16 a + j][n = n0 + wn BN/2 + 16 b + 4 g + 0..3]
+  // One k-step t.  Load queue order: x(t+1) [issued in step t-1 behind its split], W(t+1), x(t+2).
+  auto step = [&](const int cur) __attribute__((always_inline)) {
+    if (advance(cw)) w_rows(cw);
+    w_dma(cur ^ 1, cw);
+    u32x4 xb[4][NP];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const long long m = m0 + wm * 64 + 16 * a + j;
-    if (m >= p.M) continue;
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int part = 0; part < NP; ++part) xb[a][part] = *reinterpret_cast<const u32x4*>(xfrag + part * 8192 + a * 1024);
+    const unsigned char* wf = wfrag + cur * WSTAGE;
+    u32x4 wa[NP];          // the first W fragments too: the MFMAs can start right behind the barrier
+#pragma unroll
+    for (int part = 0; part < NP; ++part) wa[part] = *reinterpret_cast<const u32x4*>(wf + part * WPART);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // every wave holds its x fragments: the x tile is free
+    asm volatile("" ::: "memory");
+    // x(t+1) has landed when at most this step's G loads of W are outstanding
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]), "+v"(px[3]) : "n"(G));
+    x_store(px);
+    if (advance(cx)) x_rows(cx);
+    x_issue(px, cx);                         // x(t+2), into the registers just split
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int n = n0 + wn * (BN / 2) + 16 * b + 4 * g;
-      if (n >= p.N) continue;            // N is a multiple of 4: a lane's four columns are all in or all out
-      f32x4 v = acc[a][b];
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      if (p.act) {
+      if (b > 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+        for (int part = 0; part < NP; ++part) wa[part] = *reinterpret_cast<const u32x4*>(wf + part * WPART + b * 1024);
       }
-      float* o = p.out + m * p.N + n;
-      if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.N + n);
-      *reinterpret_cast<f32x4*>(o) = v;
+      if constexpr (NP == 3) {
+        // six cross products, smallest first: (A part, B part) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); A = W, B = x
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_bf16(wa[PA[term]], xb[a][PB[term]], acc[a][b]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_bf16(wa[0], xb[a][0], acc[a][b]);
+      }
     }
-  }
+    // W(t+1) has landed when at most the 4 x loads issued behind it are outstanding
+    if (cc.ks == nk - 1) {
+      if (p.resid) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    }
+    advance(cc);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // W(t+1) is in its buffer (queued behind it: x(t+2))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the x tile and W buffer writes are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  for (long long t = 0; t < total; ++t) step((int)(t & 1));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the prefetches issued past the end
 }
 
 // weights [N][K] fp32 -> three bf16 images [N][K]
@@ -171,6 +319,39 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restric
     reinterpret_cast<unsigned*>(m)[i] = mm;
     reinterpret_cast<unsigned*>(l)[i] = ll;
   }
+}
+
+
+template <int BN, int NP>
+static int32_t launch_v2(const Params& p, hipStream_t s) {
+  static int slots = 0;      // resident workgroups on the device (2 per CU by LDS), found once
+  constexpr size_t lds = (size_t)NP * 8192 + 2 * (size_t)NP * BN * 64;
+  auto kern = linear_kernel<BN, NP>;
+  if (!slots) {
+    DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dev = 0, cus = 0, per_cu = 0;
+    DLWP_HIP_CHECK(hipGetDevice(&dev));
+    DLWP_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    DLWP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
+    DLWP_REQUIRE(per_cu > 0 && cus >= 8, DLWP_ERR_UNSUPPORTED, "linear: kernel does not fit on this device");
+    slots = cus * per_cu;
+  }
+  const long long tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  long long per_xcd = ((tiles_m + 7) / 8) * tiles_n;      // the busiest XCD's tile count
+  DLWP_REQUIRE(per_xcd < (1ll << 30) && 3ll * p.wpart * 2 < (1ll << 31) && (long long)BM * p.K * 4 < (1ll << 31),
+               DLWP_ERR_UNSUPPORTED, "linear: operand too large for 32-bit tile offsets");
+  if (per_xcd > slots / 8) per_xcd = slots / 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * per_xcd)), dim3(256), lds, s, p);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
+// form 3: fp32-accurate (six products), 1: bf16 operands
+static int32_t launch(const Params& p, int form, hipStream_t s) {
+  // 96-wide W tiles where 128 would waste a quarter or more of the last tile (N = 96, 192, 288, 576, 1152)
+  const bool narrow = (p.N % 128) != 0 && (p.N % 128) <= 96 && (p.N % 96 == 0 || p.N < 128);
+  if (form == 3) return narrow ? launch_v2<96, 3>(p, s) : launch_v2<128, 3>(p, s);
+  return narrow ? launch_v2<96, 1>(p, s) : launch_v2<128, 1>(p, s);
 }
 
 }  // namespace lin
@@ -201,9 +382,8 @@ extern "C" int32_t dlwp_linear_pack_f32(const float* weight_dev, int32_t out_fea
   return DLWP_OK;
 }
 
-extern "C" int32_t dlwp_linear_f32(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
-                                   float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
-                                   void* stream) {
+static int32_t linear_run(int form, const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                          float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act, void* stream) {
   DLWP_REQUIRE(x_dev && packed_dev && out_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(rows > 0, DLWP_ERR_INVALID_ARGUMENT, "rows must be positive");
   DLWP_REQUIRE(act == 0 || act == 1, DLWP_ERR_INVALID_ARGUMENT, "linear: act must be 0 (none) or 1 (GELU)");
@@ -216,30 +396,22 @@ extern "C" int32_t dlwp_linear_f32(const float* x_dev, const void* packed_dev, c
                DLWP_ERR_INVALID_ARGUMENT, "pointers must be 16-byte aligned");
   lin::Params p;
   const size_t part = bytes / 3;
-  const char* b = reinterpret_cast<const char*>(packed_dev);
-  p.w = reinterpret_cast<const unsigned short*>(b);
+  p.w = reinterpret_cast<const unsigned short*>(packed_dev);
   p.wpart = (long long)(part / 2);
   p.x = x_dev; p.bias = bias_dev; p.resid = resid_dev; p.out = out_dev;
   p.M = rows; p.N = out_features; p.K = in_features; p.act = act;
-  const long long tiles_m = (rows + lin::BM - 1) / lin::BM;
-  // 128-wide W tiles unless that wastes a quarter or more of the last one (N = 192, 576, ...)
-  const bool wide = (out_features % 128) == 0 || (out_features % 128) > 96;
-  const long long tiles_n = wide ? (out_features + 127) / 128 : (out_features + 63) / 64;
-  DLWP_REQUIRE(tiles_m * tiles_n < (1ll << 31), DLWP_ERR_UNSUPPORTED, "linear: too many tiles");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const long long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;     // m-tile slabs in groups of 8 (one per XCD)
-  DLWP_REQUIRE(grid < (1ll << 31), DLWP_ERR_UNSUPPORTED, "linear: too many tiles");
-  if (wide) {
-    constexpr size_t lds = (size_t)3 * (lin::BM + 128) * lin::LDT * 2;
-    DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lin::linear_bf16x6_kernel<128>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(lin::linear_bf16x6_kernel<128>, dim3((unsigned)grid), dim3(256), lds, s, p);
-  } else {
-    constexpr size_t lds = (size_t)3 * (lin::BM + 64) * lin::LDT * 2;
-    DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lin::linear_bf16x6_kernel<64>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(lin::linear_bf16x6_kernel<64>, dim3((unsigned)grid), dim3(256), lds, s, p);
-  }
-  DLWP_HIP_CHECK(hipGetLastError());
-  return DLWP_OK;
+  return lin::launch(p, form, s);
+}
+
+extern "C" int32_t dlwp_linear_f32(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                                   float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
+                                   void* stream) {
+  return linear_run(3, x_dev, packed_dev, bias_dev, resid_dev, out_dev, rows, in_features, out_features, act, stream);
+}
+
+extern "C" int32_t dlwp_linear_bf16(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                                    float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
+                                    void* stream) {
+  return linear_run(1, x_dev, packed_dev, bias_dev, resid_dev, out_dev, rows, in_features, out_features, act, stream);
 }

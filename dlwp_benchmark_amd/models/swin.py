@@ -64,7 +64,7 @@ class _Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self.attention_precision = "fp32"
-        self.linear_form = "bf16x6"      # "bf16x6": dlwp_linear_f32; "rocblas": fp32 rocBLAS GEMMs (cross-check / A-B timing)
+        self.linear_form = "bf16x6"      # "bf16x6": dlwp_linear_f32; "bf16": dlwp_linear_bf16; "rocblas": fp32 rocBLAS GEMMs
 
     def forward(self, x, h, w, pend=None):
         """x holds (true x - pend); returns (x, pend) in the same convention (pend None = nothing pending)."""
@@ -90,15 +90,17 @@ class _Block(nn.Module):
                                      precision=self.attention_precision)
             x = x + self.attn.proj(a)
             return x + self.mlp(self.norm2(x)), None
-        if self.linear_form == "bf16x6" and ops.attention_block_linears_supported(self.dim, self.mlp.fc1.out_features):
-            # the four Linears as dlwp_linear_f32 (fp32-accurate GEMM on the bf16 pipe), bias / GELU / residual adds in their
-            # epilogues, in place on x
+        if self.linear_form != "rocblas" and ops.attention_block_linears_supported(self.dim, self.mlp.fc1.out_features):
+            # the four Linears as dlwp_linear_f32 (fp32-accurate GEMM on the bf16 pipe) or dlwp_linear_bf16, bias / GELU /
+            # residual adds in their epilogues, in place on x
+            prec = "bf16" if self.linear_form == "bf16" else "fp32"
             if pend is not None:
                 x.add_(pend)
-            qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), self.attn.qkv)
+            qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), self.attn.qkv,
+                             precision=prec)
             a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.relative_position_bias_table, spec,
                                      precision=self.attention_precision)
-            return ops.attention_block_tail(x, a, self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2), None
+            return ops.attention_block_tail(x, a, self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2, precision=prec), None
         # rocBLAS form: residual adds as GEMM accumulation in place on x, Linear biases deferred into `pend`
         # (ops.residual_block_tail)
         qkv = self.attn.qkv(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre_bias=pend))
@@ -224,8 +226,9 @@ class SwinTransformer(HipBackbone):
 
     def set_linear_form(self, form: str):
         """"bf16x6" (default): the blocks' Linears run dlwp_linear_f32 (fp32-accurate on the bf16 matrix pipe, fused epilogues);
-        "rocblas": torch's fp32 GEMMs.  Each is the other's cross-check.  Per-module state."""
-        if form not in ("bf16x6", "rocblas"):
+        "rocblas": torch's fp32 GEMMs (each is the other's cross-check); "bf16": dlwp_linear_bf16 (bf16 operands, fp32
+        accumulation -- nn.Linear under autocast(bfloat16)).  Per-module state."""
+        if form not in ops.LINEAR_FORMS:
             raise _lib.DlwpError(f"unknown linear form {form!r}")
         for m in self.modules():
             if hasattr(m, "linear_form"):

@@ -683,10 +683,14 @@ class LinearWeights:
 
 
 def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x @ m.weight.T + m.bias) + resid over the last dimension in one launch (dlwp_linear_f32: fp32-accurate GEMM on the
-    bf16 matrix pipe; act 0 none / 1 exact GELU).  `out` may be `resid` (in-place residual add).  With gradients wanted the
-    torch operators run instead (training.py's convention)."""
+           out: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
+    """act(x @ m.weight.T + m.bias) + resid over the last dimension in one launch; act 0 none / 1 exact GELU.
+    precision "fp32": dlwp_linear_f32, fp32-accurate GEMM on the bf16 matrix pipe (six products of exact three-way splits);
+    "bf16": dlwp_linear_bf16, bf16 operands and fp32 accumulation (what autocast(bfloat16) makes of nn.Linear).
+    `out` may be `resid` (in-place residual add).  With gradients wanted the torch operators run instead (training.py's
+    convention)."""
+    if precision not in ("fp32", "bf16"):
+        raise _lib.DlwpError(f"linear: unknown precision {precision!r}")
     from . import training as _T
     if _T.wants_grad(x, m.weight, m.bias, resid):
         y = torch.nn.functional.linear(x, m.weight, m.bias)
@@ -720,17 +724,21 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
         raise _lib.DlwpError("linear: out must not alias x")
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        _lib.check(lib.dlwp_linear_f32(x.data_ptr(), packed.data_ptr(),
-                                       m.bias.contiguous().data_ptr() if m.bias is not None else None,
-                                       resid.data_ptr() if resid is not None else None, out.data_ptr(),
-                                       x.numel() // k, k, n, int(act), _lib.stream_ptr()), "dlwp_linear_f32")
+        fn = lib.dlwp_linear_bf16 if precision == "bf16" else lib.dlwp_linear_f32
+        _lib.check(fn(x.data_ptr(), packed.data_ptr(), m.bias.contiguous().data_ptr() if m.bias is not None else None,
+                      resid.data_ptr() if resid is not None else None, out.data_ptr(), x.numel() // k, k, n, int(act),
+                      _lib.stream_ptr()), "dlwp_linear_" + ("bf16" if precision == "bf16" else "f32"))
     return out
 
 
+LINEAR_FORMS = ("bf16x6", "bf16", "rocblas")
+
+
 def linear_as(form: str, x: torch.Tensor, m: torch.nn.Linear) -> torch.Tensor:
-    """m(x) through dlwp_linear_f32 when form == "bf16x6" and the shape is covered, else the module itself (rocBLAS)."""
-    if form == "bf16x6" and x.is_cuda and linear_supported(m.in_features, m.out_features):
-        return linear(x, m)
+    """m(x) through dlwp_linear_f32 (form "bf16x6") / dlwp_linear_bf16 ("bf16") when the shape is covered, else the module
+    itself (rocBLAS fp32)."""
+    if form in ("bf16x6", "bf16") and x.is_cuda and linear_supported(m.in_features, m.out_features):
+        return linear(x, m, precision="bf16" if form == "bf16" else "fp32")
     return m(x)
 
 
@@ -740,14 +748,14 @@ def attention_block_linears_supported(dim: int, hidden: int) -> bool:
 
 
 def attention_block_tail(x: torch.Tensor, attn_out: torch.Tensor, proj: torch.nn.Linear, norm2: torch.nn.LayerNorm,
-                         fc1: torch.nn.Linear, fc2: torch.nn.Linear) -> torch.Tensor:
+                         fc1: torch.nn.Linear, fc2: torch.nn.Linear, precision: str = "fp32") -> torch.Tensor:
     """`x = x + proj(attn_out); x = x + fc2(gelu(fc1(norm2(x))))` of a Swin / Pangu block (swin_transformer.py:254-262,
     panguweather.py:318-322), IN PLACE on x: three dlwp_linear_f32 launches (bias, GELU and both residual adds in the GEMM
     epilogues) and one LayerNorm."""
-    linear(attn_out, proj, resid=x, out=x)
+    linear(attn_out, proj, resid=x, out=x, precision=precision)
     n2 = layer_norm(x, norm2.weight, norm2.bias, norm2.eps)
-    hid = linear(n2, fc1, act=1)
-    linear(hid, fc2, resid=x, out=x)
+    hid = linear(n2, fc1, act=1, precision=precision)
+    linear(hid, fc2, resid=x, out=x, precision=precision)
     return x
 
 

@@ -316,6 +316,10 @@ size_t dlwp_linear_packed_bytes(int32_t out_features, int32_t in_features);
 int32_t dlwp_linear_pack_f32(const float* weight_dev, int32_t out_features, int32_t in_features, void* packed_dev, void* stream);
 int32_t dlwp_linear_f32(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
                         float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act, void* stream);
+/* The same Linear with bf16 operands (x rounded to bf16 on the fly, the first bf16 image of the weight) and fp32
+ * accumulation -- what torch.autocast(bfloat16) makes of nn.Linear; one matrix-pipe product instead of six. */
+int32_t dlwp_linear_bf16(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                         float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The remaining U-Net / ModernUNet operators (csrc/conv2.hip), NCHW fp32, activations as above.

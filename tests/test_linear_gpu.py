@@ -46,6 +46,29 @@ def test_linear_matches_float64(rows, k, n, bias, act, resid):
     assert (got.double() - want).abs().max() <= 2e-5 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,k,n,act,resid", [(1000, 96, 288, 0, False), (4096, 384, 96, 0, True), (2051, 192, 768, 1, False),
+                                                 (300, 32, 100, 1, True)])
+def test_linear_bf16_matches_bf16_rounded_operands(rows, k, n, act, resid):
+    """dlwp_linear_bf16: operands rounded to bf16 (round to nearest even, like torch's .bfloat16()), products and sums in
+    fp32 -- against the same rounding done in torch and the GEMM in float64."""
+    from dlwp_benchmark_amd import ops
+
+    m = _linear(k, n, True, seed=rows + k)
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, k, generator=g) * 2.0 + 0.3).to(DEV)
+    r = torch.randn(rows, n, generator=g).to(DEV) if resid else None
+    with torch.no_grad():
+        got = ops.linear(x, m, act=act, resid=r, precision="bf16")
+        want = F.linear(x.bfloat16().double(), m.weight.bfloat16().double(), m.bias.double())
+        if act:
+            want = F.gelu(want)
+        if resid:
+            want = want + r.double()
+        full = F.linear(x.double(), m.weight.double(), m.bias.double())
+    assert rel_l2(got, want) <= 1e-6
+    assert 1e-4 < rel_l2(F.linear(x.bfloat16().double(), m.weight.bfloat16().double(), m.bias.double()), full) < 1e-2   # it IS bf16
+
+
 def test_linear_in_place_residual_and_leading_dims():
     from dlwp_benchmark_amd import ops
 
@@ -125,3 +148,7 @@ def test_block_linear_forms_hold_the_reference_bound(tag):
         errs = per_step_rel_l2(outs[form], want)
         assert max(errs) <= 1e-5, f"{tag} {form}: per-step rel L2 {['%.2e' % e for e in errs]}"
     assert rel_l2(outs["bf16x6"], outs["rocblas"]) <= 5e-6
+    # bf16 Linear operands: the bound the bf16 attention line uses (tests/test_backbones_gpu.py)
+    model.set_linear_form("bf16")
+    got = model(constants=dev(constants), prescribed=dev(prescribed), prognostic=dev(prognostic))
+    assert max(per_step_rel_l2(got, want)) <= 5e-3

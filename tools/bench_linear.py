@@ -37,10 +37,14 @@ def timed(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="", help="substring of the shape label")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"))
     args = ap.parse_args()
     dev = "cuda:0"
     print(f"{'shape':18s} {'rows':>8s} {'in':>5s} {'out':>5s} | {'hip us':>8s} {'TF/s(6x)':>9s} | {'torch us':>9s} | err hip / torch")
     for label, rows, k, n, act, resid in SHAPES:
+        if args.only and args.only not in label:
+            continue
         torch.manual_seed(0)
         m = torch.nn.Linear(k, n).to(dev)
         x = torch.randn(rows, k, device=dev)
@@ -48,7 +52,7 @@ def main():
         out = torch.empty(rows, n, device=dev)
         with torch.no_grad():
             def hip():
-                ops.linear(x, m, act=act, resid=r, out=out)
+                ops.linear(x, m, act=act, resid=r, out=out, precision=args.precision)
 
             def ref():
                 y = torch.nn.functional.linear(x, m.weight, m.bias)
