@@ -498,6 +498,10 @@ size_t wattn2_workspace_bytes(const dlwp_wattn_desc* u, int batch, int np);
 int32_t wattn2_run(const dlwp_wattn_desc* u, const float* qkv, const float* table, float* out, int batch, void* workspace,
                    size_t workspace_bytes, hipStream_t s, int np);
 const int* wattn2_fallback_counter(const dlwp_wattn_desc* u, int batch, int np, const void* workspace);
+// window_attn3.hip: the small 3-D windows of Pangu's earth-specific attention (bias_mode 1, head_dim 32)
+size_t wattn3_workspace_bytes(const dlwp_wattn_desc* u, int batch, int np);
+int32_t wattn3_run(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias, const float* table, float* out, int batch,
+                   void* workspace, size_t workspace_bytes, hipStream_t s, int np);
 }
 
 using namespace dlwp;
@@ -606,7 +610,8 @@ static int32_t window_attn_impl(const dlwp_wattn_desc* u, const float* qkv, cons
 extern "C" size_t dlwp_window_attn_workspace_bytes(const dlwp_wattn_desc* u, int32_t batch, int32_t bf16) {
   if (!u || batch <= 0) return 0;
   if (!bf16 && u->form == 0) return 0;     // the fp32-MFMA form is the generic kernel
-  return wattn2_workspace_bytes(u, batch, bf16 ? 1 : 3);
+  const size_t w2 = wattn2_workspace_bytes(u, batch, bf16 ? 1 : 3);
+  return w2 ? w2 : wattn3_workspace_bytes(u, batch, bf16 ? 1 : 3);
 }
 
 extern "C" int32_t dlwp_window_attn_fallbacks(const dlwp_wattn_desc* u, int32_t batch, int32_t bf16, const void* workspace,
@@ -632,7 +637,10 @@ extern "C" int32_t dlwp_window_attn_f32(const dlwp_wattn_desc* u, const float* q
   if (u->form != 0 && qkv && table && out && batch > 0) {
     // 2-D windows (every Swin block): the second-generation kernel (bf16x6 operands, bias through the accumulator,
     // masked tiles skipped); returns 1 when the descriptor or the workspace does not fit -> generic kernel below
-    const int32_t rc = wattn2_run(u, qkv, table, out, batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 3);
+    int32_t rc = wattn2_run(u, qkv, table, out, batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 3);
+    if (rc != 1) return rc;
+    // small 3-D windows with the earth-specific bias (every Pangu block): the third kernel, same convention
+    rc = wattn3_run(u, qkv, qkv_bias, table, out, batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 3);
     if (rc != 1) return rc;
   }
   return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, x6 ? 2 : 0);
@@ -642,7 +650,9 @@ extern "C" int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* u, const float* 
                                          const float* table, float* out, int32_t batch, void* workspace,
                                          size_t workspace_bytes, void* stream) {
   if (u && qkv && table && out && batch > 0) {
-    const int32_t rc = wattn2_run(u, qkv, table, out, batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 1);
+    int32_t rc = wattn2_run(u, qkv, table, out, batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 1);
+    if (rc != 1) return rc;
+    rc = wattn3_run(u, qkv, qkv_bias, table, out, batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 1);
     if (rc != 1) return rc;
   }
   return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, 1);

@@ -76,3 +76,80 @@ def test_exponent_slack_fallback_is_exact(shifted):
     assert torch.isfinite(got).all()
     # logits of magnitude ~430 (log2 units) carry an fp32 rounding error of ~3e-5 each in EITHER implementation
     assert rel_l2(got, want) <= 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# third kernel (csrc/window_attn3.hip): small 3-D windows with the earth-specific bias (every Pangu block)
+# ---------------------------------------------------------------------------------------------------------------------
+def _earth_spec(grid, window, heads, shifted):
+    """The descriptor models/pangu.py builds for a block (panguweather.py:285-316): ZeroPad3d to the window, roll by half a
+    window on all three axes with the reference's asymmetric forward / backward longitude shift, shift_window_mask.py regions."""
+    from dlwp_benchmark_amd import ops
+    from dlwp_benchmark_amd.models.pangu import _pad3d
+
+    p = _pad3d(grid, window)
+    padded = (grid[0] + p[4] + p[5], grid[1] + p[2] + p[3], grid[2] + p[0] + p[1])
+    shift = tuple(w // 2 for w in window)
+    roll = shifted and all(shift)
+    spl, slat, slon = shift
+    ppl, plat, plon = padded
+    wpl, wlat, wlon = window
+    spec = ops.WindowSpec(
+        grid=grid, padded=padded, pad_lead=(p[4], p[2], p[0]), window=window,
+        shift_fwd=(spl, slat, slat) if roll else (0, 0, 0), shift_back=(spl, slat, slon) if roll else (0, 0, 0), use_mask=roll,
+        mask_b1=(ppl - wpl, plat - wlat, plon + slon - wlon) if roll else (ops.BIG,) * 3,
+        mask_b2=(ppl - spl, plat - slat, plon) if roll else (ops.BIG,) * 3,
+        bias_mode=1, heads=heads, head_dim=32, scale=32 ** -0.5)
+    rows = wpl * wpl * wlat * wlat * (2 * wlon - 1)
+    types = (padded[0] // wpl) * (padded[1] // wlat)
+    return spec, rows, types
+
+
+@pytest.mark.parametrize("grid,window", [((1, 16, 32), (2, 6, 12)),      # the reference's shape class: one level, padded everywhere
+                                         ((2, 12, 24), (2, 6, 12)),      # two real levels: both planes are query planes
+                                         ((1, 8, 16), (1, 4, 8)),        # one plane, no padding
+                                         ((2, 11, 13), (2, 5, 7)),       # 35 tokens per plane (3 blocks), odd pads
+                                         ((1, 9, 30), (2, 3, 10))])      # 30 tokens per plane (2 blocks)
+@pytest.mark.parametrize("shifted", [False, True])
+def test_earth_window_kernel_matches_generic_kernel(grid, window, shifted):
+    import ctypes
+
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd import ops
+
+    heads, b = 3, 2
+    spec, rows, types = _earth_spec(grid, window, heads, shifted)
+    g = torch.Generator().manual_seed(7)
+    ltok = grid[0] * grid[1] * grid[2]
+    qkv = torch.randn(b, ltok, 3, heads, 32, generator=g)
+    qkv[:, :, :2] *= 1.5
+    qkv = qkv.reshape(b, ltok, 3 * heads * 32).cuda()
+    bias = (torch.randn(3 * heads * 32, generator=g) * 0.3).cuda()
+    table = (torch.randn(rows, types, heads, generator=g) * 0.5).cuda()
+    dsc = spec.to_c()
+    dsc.form = 1
+    assert L.load().dlwp_window_attn_workspace_bytes(ctypes.byref(dsc), b, 0) > 0, "descriptor should run on the earth-window kernel"
+    want = ops.window_attention(qkv, bias, table, spec, precision="fp32_mfma")       # generic kernel, fp32 MFMA
+    got = ops.window_attention(qkv, bias, table, spec, precision="bf16x6")
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) <= 2e-6
+    got16 = ops.window_attention(qkv, bias, table, spec, precision="bf16")
+    e = rel_l2(got16, want)
+    assert 1e-6 < e <= 2e-2, e
+
+
+def test_earth_window_kernel_large_logits():
+    """Logits in the hundreds: the exact row maximum keeps the exponentials in range (no slack to leave on this path)."""
+    from dlwp_benchmark_amd import ops
+
+    spec, rows, types = _earth_spec((1, 16, 32), (2, 6, 12), 2, True)
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(1, 512, 3, 2, 32, generator=g)
+    qkv[:, :, :2] *= 6.0
+    qkv = qkv.reshape(1, 512, 192).cuda()
+    bias = (torch.randn(192, generator=g) * 0.3).cuda()
+    table = (torch.randn(rows, types, 2, generator=g) * 20.0).cuda()
+    want = ops.window_attention(qkv, bias, table, spec, precision="fp32_mfma")
+    got = ops.window_attention(qkv, bias, table, spec, precision="bf16x6")
+    assert torch.isfinite(got).all() and rel_l2(got, want) <= 2e-4      # fp32 rounding of logits of several hundred
