@@ -164,6 +164,8 @@ def _attn_tag(name, a):
     if name.startswith("dlwp_window_attn"):
         d = a[0]._obj
         return (tuple(d.padded), tuple(d.window), int(d.heads), int(d.head_dim), int(a[5]), int(d.use_mask))   # a[5] = batch
+    if name.startswith("dlwp_linear_") and not name.endswith("pack_f32"):
+        return (int(a[5]), int(a[6]), int(a[7]), int(a[8]), a[3] is not None)      # rows, in, out, act, residual operand
     return None
 
 
@@ -256,10 +258,34 @@ def bench_other_configs(device, only=None, reps=2):
                                                         sorted(by_name.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}
             entry["share_outside_libdlwp_hip"] = max(0.0, 1.0 - covered / (dt * 1e3))   # rocBLAS / MIOpen / torch glue
             entry["roofline"] = _other_roofline(cls, cfg, batch, h, w, summ, prec)
+            lin = _linear_roofline(summ)
+            if lin is not None:
+                entry["roofline_linear"] = lin
             res[tag + {"fp32": "", "bf16": "_bf16attn", "bf16all": "_bf16"}[variant]] = entry
         del model, out
         torch.cuda.empty_cache()
     return res
+
+
+def _linear_roofline(summ):
+    """the Linear kernel's costliest shape class: algorithmic flops 2 M K N (bias / GELU / residual not counted) / event time,
+    priced against the fp32 matrix peak for dlwp_linear_f32 (fp32-accurate: six bf16 products per fp32 one are not credited)
+    and against the dense bf16 peak for dlwp_linear_bf16."""
+    lin = {k: v for k, v in summ.items() if k[0] in ("dlwp_linear_f32", "dlwp_linear_bf16")}
+    if not lin:
+        return None
+    (name, tag), v = max(lin.items(), key=lambda kv: kv[1]["total_ms"])
+    rows, k, n, act, resid = tag
+    fl = 2.0 * rows * k * n
+    by = 4.0 * rows * (k + n * (2 if resid else 1))
+    peak = MFMA_BF16_PEAK_TF if name.endswith("bf16") else MFMA_F32_PEAK_TF
+    ach = fl / (v["avg_ms"] * 1e-3) / 1e12
+    tot = sum(x["total_ms"] for x in lin.values())
+    return {"kernel": f"linear_kernel via {name} ({rows} x {k} -> {n}{', GELU' if act else ''}{', + residual' if resid else ''})",
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+            "hbm_view_GBps": by / (v["avg_ms"] * 1e-3) / 1e9, "avg_launch_ms": v["avg_ms"], "launches_per_rollout": v["calls"],
+            "all_linear_ms_per_rollout": tot}
 
 
 def _other_roofline(cls, cfg, batch, h, w, summ, prec):
