@@ -91,21 +91,23 @@ __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
 
 // GELU (exact, erf form: torch.nn.functional.gelu default) without a libm call.
 //   gelu(x) = 0.5 x (1 + erf(x/sqrt2)) = max(x, 0) - |x| * (0.5 erfc(|x|/sqrt2))
-//   0.5 erfc(u/sqrt2), u >= 0, is evaluated as exp2(u * Q(u) - 1) with a degree-8 polynomial (fitted to
-//   -log2(erfc(t))/t on t in [0, 4.5] and re-expressed in u = sqrt2 t; u clamped at 4.5 sqrt2, where
-//   erfc = 2e-10).  Max abs error of the GELU value 2.6e-7 in fp32 (tests/test_gelu_poly.py).
+//   0.5 erfc(u/sqrt2), u >= 0, is evaluated as exp2(u * Q(u) - 1) with a degree-5 polynomial Q fitted to
+//   (log2(0.5 erfc(u/sqrt2)) + 1) / u on u in [0, 4.5 sqrt2] (iteratively re-weighted towards the minimax of the GELU error;
+//   u clamped at 4.5 sqrt2, where erfc = 2e-10).  Approximation error of the GELU value 8.7e-8; evaluated in fp32 the error
+//   is 5.3e-7 -- set by the rounding of the exponent u Q(u), up to 30, NOT by the degree: the degree-8 polynomial this
+//   replaced in round 2 reached 4.8e-7 with three more multiply-adds per element (tests/test_gelu_poly.py).  GELU issue
+//   slots are the largest single vector cost of the FNO step (640 evaluations per grid point and step).
 // The fp32 matrix instructions run on the same fp32 lanes as the VALU (they do not overlap,
 // tools/ubench_fp32.hip), so GELU issue slots are as expensive as MFMA cycles: the 8-wide form below
-// uses packed fp32 and costs ~8.5 issue slots per element (libm-free scalar code: ~19).
+// uses packed fp32 and costs ~7 issue slots per element (libm-free scalar code: ~19).
 #define DLWP_GELU_UMAX 6.3639610306789276f
-#define DLWP_GELU_Q8 2.493533486e-07f
+#define DLWP_GELU_QTOP 2.992443883e-05f
 #define DLWP_GELU_COEFFS(X)                                                                    \
-  X(-5.790222076e-06f) X(5.344793681e-05f) X(-2.209076483e-04f) X(-8.910115139e-05f)           \
-  X(7.026572246e-03f) X(-5.248115212e-02f) X(-4.592110217e-01f) X(-1.151105046e+00f)
+  X(-7.398762886e-04f) X(7.977468945e-03f) X(-5.323819506e-02f) X(-4.589156813e-01f) X(-1.151147084e+00f)
 
 __device__ __forceinline__ float gelu_erf(float x) {
   const float u = fminf(fabsf(x), DLWP_GELU_UMAX);
-  float p = DLWP_GELU_Q8;
+  float p = DLWP_GELU_QTOP;
 #define DLWP_STEP(c) p = fmaf(p, u, c);
   DLWP_GELU_COEFFS(DLWP_STEP)
 #undef DLWP_STEP
@@ -130,7 +132,7 @@ __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
   t0 = fminf(fabsf(x0), umax); t2 = fminf(fabsf(x2), umax); t4 = fminf(fabsf(x4), umax); t6 = fminf(fabsf(x6), umax);
   t1 = fminf(fabsf(x1), umax); t3 = fminf(fabsf(x3), umax); t5 = fminf(fabsf(x5), umax); t7 = fminf(fabsf(x7), umax);
   const f32x2 ta = {t0, t1}, tb = {t2, t3}, tc = {t4, t5}, td = {t6, t7};
-  f32x2 pa = {DLWP_GELU_Q8, DLWP_GELU_Q8}, pb = pa, pc = pa, pd = pa;
+  f32x2 pa = {DLWP_GELU_QTOP, DLWP_GELU_QTOP}, pb = pa, pc = pa, pd = pa;
 #define DLWP_PKSTEP4(cf)                                                                       \
   {                                                                                            \
     const f32x2 cc = {cf, cf};                                                                 \
@@ -172,7 +174,7 @@ __device__ __forceinline__ void gelu_erf8_fma(f32x4& u, f32x4& v) {
   const float t0 = fminf(fabsf(x0), umax), t1 = fminf(fabsf(x1), umax), t2 = fminf(fabsf(x2), umax),
               t3 = fminf(fabsf(x3), umax), t4 = fminf(fabsf(x4), umax), t5 = fminf(fabsf(x5), umax),
               t6 = fminf(fabsf(x6), umax), t7 = fminf(fabsf(x7), umax);
-  float p0 = DLWP_GELU_Q8, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
+  float p0 = DLWP_GELU_QTOP, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
 #define DLWP_FSTEP1(p, t, cf) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(t), "s"(cf));
 #define DLWP_FSTEP8(cf)                                                                        \
   {                                                                                            \
