@@ -285,7 +285,8 @@ def _linear_roofline(summ):
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
             "hbm_view_GBps": by / (v["avg_ms"] * 1e-3) / 1e9, "avg_launch_ms": v["avg_ms"], "launches_per_rollout": v["calls"],
-            "all_linear_ms_per_rollout": tot}
+            "all_linear_ms_per_rollout": tot,
+            "note": "dlwp_linear_f32 runs its products on the bf16 pipe: against the fp32 matrix peak its fraction can exceed 1"}
 
 
 def _other_roofline(cls, cfg, batch, h, w, summ, prec):

@@ -16,8 +16,10 @@ __global__ __launch_bounds__(256) void patch_embed_1x1_kernel(const float* __res
                                                              const float* __restrict__ pos, float* __restrict__ out,
                                                              long long B, int cin, long long HW, int C) {
   const int lane = threadIdx.x & 63;
-  const int lpt = C >> 2, tpw = 64 / lpt;          // lanes per token (4 channels each), tokens per wave
-  const int sub = lane % lpt, tl = lane / lpt;
+  const int lpt = C >> 2, tpw = 64 / lpt;          // lanes per token (4 channels each), tokens per wave (64 % lpt lanes idle)
+  const int tl = lane / lpt;
+  const bool active = tl < tpw;
+  const int sub = active ? lane % lpt : 0;
   float wr[CIN_MAX][4];
 #pragma unroll
   for (int ci = 0; ci < CIN_MAX; ++ci)
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void patch_embed_1x1_kernel(const float* __res
       for (int ci = 0; ci < CIN_MAX; ++ci)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[u][k] = fmaf(wr[ci][k], xv[u][ci], acc[u][k]);
-      if (tok[u] < total) *reinterpret_cast<f32x4*>(out + tok[u] * C + 4 * sub) = acc[u];
+      if (active && tok[u] < total) *reinterpret_cast<f32x4*>(out + tok[u] * C + 4 * sub) = acc[u];
     }
   }
 }
@@ -63,8 +65,8 @@ extern "C" int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_d
   DLWP_REQUIRE(x_dev && w_dev && out_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0 && in_channels > 0 && tokens > 0 && channels > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
   DLWP_REQUIRE(in_channels <= 32, DLWP_ERR_UNSUPPORTED, "patch embed: in_channels %d > 32", in_channels);
-  DLWP_REQUIRE(channels >= 4 && channels <= 256 && (channels & (channels - 1)) == 0, DLWP_ERR_UNSUPPORTED,
-               "patch embed: channels %d (power of two in [4, 256])", channels);
+  DLWP_REQUIRE(channels >= 4 && channels <= 256 && channels % 4 == 0, DLWP_ERR_UNSUPPORTED,
+               "patch embed: channels %d (a multiple of 4 in [4, 256])", channels);
   const long long total = (long long)batch * tokens;
   const int tpw = 64 / (channels / 4);
   long long blocks = (total + (long long)tpw * 4 * 4 - 1) / ((long long)tpw * 4 * 4);   // 4 waves x 4 groups per block pass

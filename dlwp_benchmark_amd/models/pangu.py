@@ -275,11 +275,19 @@ class PanguWeather(HipBackbone):
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:
         """panguweather.py:512-535 (`forward_one_step`)."""
-        x = self.patchembed2d(x)
-        b, c, lat, lon = x.shape
-        # token-major ONCE: a transposed view here made every kernel / residual add of layer 1 copy or inherit the
-        # permuted strides again (4 full-size copies per step in the profile)
-        x = x.reshape(b, c, -1).transpose(1, 2).contiguous()
+        pe = self.patchembed2d
+        infer = not (self.training and torch.is_grad_enabled())
+        if infer and pe.patch_size == (1, 1) and x.is_cuda and ops.patch_embed_1x1_supported(pe.proj.in_channels, pe.proj.out_channels):
+            # 1x1 patches: the embedding straight into token-major layout (no MIOpen convolution, no transposed copy)
+            b, _, lat, lon = x.shape
+            c = pe.proj.out_channels
+            x = ops.patch_embed_1x1(x, pe.proj.weight, pe.proj.bias, None)
+        else:
+            x = pe(x)
+            b, c, lat, lon = x.shape
+            # token-major ONCE: a transposed view here made every kernel / residual add of layer 1 copy or inherit the
+            # permuted strides again (4 full-size copies per step in the profile)
+            x = x.reshape(b, c, -1).transpose(1, 2).contiguous()
         x = self.layer1(x)
         skip = x
         x = self.layer3(self.layer2(self.downsample(x)))
@@ -291,11 +299,46 @@ class PanguWeather(HipBackbone):
             # full-size concat, a transposed copy of it and a convolution (panguweather.py:533-535, patch_recovery.py:5-33)
             w2 = pr.conv.weight[:, :, 0, 0]                       # [2C, Cg]
             cc = x.shape[-1]
-            y = torch.addmm(pr.conv.bias, x.reshape(-1, cc), w2[:cc])
-            y.addmm_(skip.reshape(-1, cc), w2[cc:])
+            form = self.layer1.blocks[0].linear_form
+            if infer and form != "rocblas" and x.is_cuda and ops.linear_supported(cc, (w2.shape[1] + 3) // 4 * 4):
+                y = self._recover_tokens(x, skip, "fp32")     # the output head stays fp32-accurate in every form
+            else:
+                y = torch.addmm(pr.conv.bias, x.reshape(-1, cc), w2[:cc])
+                y.addmm_(skip.reshape(-1, cc), w2[cc:])
             return y.view(b, lat, lon, -1).permute(0, 3, 1, 2).contiguous()
         out = torch.cat([x, skip], dim=-1).transpose(1, 2).reshape(b, -1, lat, lon)
         return pr(out)
+
+    def _recover_tokens(self, x, skip, precision):
+        """The 1x1 patch recovery as two dlwp_linear_* launches on the token-major tensors (the second accumulates onto the
+        first through the residual operand); the output width is padded to a multiple of 4 with zero columns."""
+        conv = self.patchrecovery2d.conv
+        w, bias = conv.weight, conv.bias
+        key = (w.data_ptr(), w._version, str(w.device), bias.data_ptr(), bias._version)
+        halves = self.__dict__.get("_recover_lin")
+        if halves is None or halves[0] != key:
+            cc, cg = x.shape[-1], w.shape[1]
+            n = (cg + 3) // 4 * 4
+            with torch.no_grad():
+                w2 = w[:, :, 0, 0]                                             # [2C, Cg]
+                wt = w2.new_zeros(2, n, cc)
+                wt[0, :cg] = w2[:cc].t()
+                wt[1, :cg] = w2[cc:].t()
+                bp = bias.new_zeros(n)
+                bp[:cg] = bias
+
+            class _Half:                      # the attributes ops.linear reads
+                pass
+
+            a, b2 = _Half(), _Half()
+            a.weight, a.bias, a.in_features, a.out_features = wt[0].contiguous(), bp, cc, n
+            b2.weight, b2.bias, b2.in_features, b2.out_features = wt[1].contiguous(), None, cc, n
+            halves = (key, a, b2, cg)
+            self.__dict__["_recover_lin"] = halves
+        _, a, b2, cg = halves
+        y = ops.linear(x.reshape(-1, x.shape[-1]), a, precision=precision)
+        y = ops.linear(skip.reshape(-1, skip.shape[-1]), b2, resid=y, out=y, precision=precision)
+        return y[:, :cg]
 
     def rollout_into(self, out, constants, prescribed, prognostic, step_begin=0, step_end=-1):
         return rollout_into(self._step_fn(), self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)

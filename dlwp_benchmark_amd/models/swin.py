@@ -235,8 +235,27 @@ class SwinTransformer(HipBackbone):
                 m.linear_form = form
         return self
 
+    def _token_decoder(self):
+        """The decoder (kernel = stride transposed convolutions + GELU, :600-612) and the 1x1 head as Linears over token-major
+        data (ops.ConvAsLinear), when every layer qualifies; None otherwise (the modules themselves run, channels-first)."""
+        if self.__dict__.get("_tok_dec") is None:
+            dec = None
+            try:
+                dec = ([ops.ConvAsLinear(seq[0]) for seq in self.decoder], ops.ConvAsLinear(self.final))
+                if not all(isinstance(seq[1], nn.GELU) and seq[1].approximate == "none" for seq in self.decoder) or \
+                        not all(ops.linear_supported(m.in_features, m.out_features) for m in dec[0] + [dec[1]]):
+                    dec = None
+            except _lib.DlwpError:
+                dec = None
+            self.__dict__["_tok_dec"] = dec if dec is not None else False
+        return self.__dict__["_tok_dec"] or None
+
     def one_step(self, x: torch.Tensor) -> torch.Tensor:
         """swin_transformer.py:645-677."""
+        dec = None if (self.training and torch.is_grad_enabled()) else self._token_decoder()
+        form = next((m.linear_form for m in self.modules() if hasattr(m, "linear_form")), "bf16x6")
+        if dec is not None and form != "rocblas" and x.is_cuda:
+            return self._one_step_tokens(x, dec, "bf16" if form == "bf16" else "fp32")
         x, h, w = self.patch_embed(x)
         outs = []
         for i, layer in enumerate(self.layers):
@@ -249,6 +268,31 @@ class SwinTransformer(HipBackbone):
         for idx, layer in enumerate(self.decoder):
             xo = layer(outs[idx] if idx == 0 else torch.cat([outs[idx], xo], dim=1))
         return self.final(xo)
+
+    def _one_step_tokens(self, x, dec, precision):
+        """one_step with everything token-major: no channels-first copies, the decoder's convolutions as dlwp_linear_* with
+        their GELU in the epilogue, the 1x1-patch embedding as dlwp_patch_embed_1x1_f32."""
+        pe = self.patch_embed
+        b = x.shape[0]
+        if pe.patch_size == (1, 1) and ops.patch_embed_1x1_supported(pe.proj.in_channels, self.embed_dim):
+            h, w = x.shape[2], x.shape[3]
+            t = ops.patch_embed_1x1(x, pe.proj.weight, pe.proj.bias, None)
+            x = pe.norm(t) if pe.norm is not None else t
+        else:
+            x, h, w = pe(x)
+        outs = []
+        for i, layer in enumerate(self.layers):
+            x_out, x, hn, wn = layer(x, h, w)
+            outs.append((getattr(self, f"norm{i}")(x_out), h, w))
+            h, w = hn, wn
+        outs = outs[::-1]
+        xo = None
+        for idx, lin in enumerate(dec[0]):
+            t, h, w = outs[idx]
+            xo = lin(t if idx == 0 else torch.cat([t, xo], dim=-1), h, w, act=1, precision=precision)
+            h, w = h * lin.k, w * lin.k
+        y = dec[1](xo, h, w, precision="fp32")                         # [B, h*w, Cg]; the output head stays fp32-accurate
+        return y.view(b, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
     def rollout_into(self, out, constants, prescribed, prognostic, step_begin=0, step_end=-1):
         return rollout_into(self._step_fn(), self.context_size, out, constants, prescribed, prognostic, step_begin, step_end)

@@ -498,7 +498,7 @@ def afno_merge(f_nchw: torch.Tensor, l_nchw: torch.Tensor, x_nhwc: torch.Tensor,
 
 
 def patch_embed_1x1_supported(in_channels: int, channels: int) -> bool:
-    return in_channels <= 32 and 4 <= channels <= 256 and channels & (channels - 1) == 0
+    return in_channels <= 32 and 4 <= channels <= 256 and channels % 4 == 0
 
 
 def patch_embed_1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
@@ -740,6 +740,63 @@ def linear_as(form: str, x: torch.Tensor, m: torch.nn.Linear) -> torch.Tensor:
     if form in ("bf16x6", "bf16") and x.is_cuda and linear_supported(m.in_features, m.out_features):
         return linear(x, m, precision="bf16" if form == "bf16" else "fp32")
     return m(x)
+
+
+class ConvAsLinear:
+    """A Conv2d / ConvTranspose2d whose kernel equals its stride (no overlap, no padding) as a Linear over the channels of
+    TOKEN-MAJOR data: ConvTranspose2d(Cin, Cout, k, k) = Linear(Cin -> k k Cout) + a pixel shuffle, Conv2d(Cin, Cout, 1) =
+    Linear(Cin -> Cout).  The derived weight / bias follow the module's parameters (data_ptr, version); out_features is
+    padded to a multiple of 4 with zero rows (dlwp_linear_f32's store width).  Used by the Swin decoder
+    (swin_transformer.py:600-612, :672-677), which the reference runs as MIOpen convolutions on channels-first copies."""
+
+    def __init__(self, conv: torch.nn.Module):
+        self.conv = conv
+        self.transposed = isinstance(conv, torch.nn.ConvTranspose2d)
+        k = conv.kernel_size
+        if k[0] != k[1] or tuple(conv.stride) != tuple(k) or conv.padding not in (0, (0, 0)) or conv.groups != 1 or \
+                conv.dilation not in (1, (1, 1)) or (not self.transposed and k[0] != 1) or \
+                (self.transposed and conv.output_padding not in (0, (0, 0))):
+            raise _lib.DlwpError(f"ConvAsLinear: {conv} is not a kernel = stride convolution")
+        self.k = k[0]
+        self.in_features = conv.in_channels
+        self.cout = conv.out_channels
+        n = self.k * self.k * self.cout if self.transposed else self.cout
+        self.out_features = (n + 3) // 4 * 4
+        self._n = n
+        self._key = None
+        self.weight = None
+        self.bias = None
+
+    def refresh(self):
+        w, b = self.conv.weight, self.conv.bias
+        key = (w.data_ptr(), w._version, str(w.device), None if b is None else (b.data_ptr(), b._version))
+        if key == self._key:
+            return
+        with torch.no_grad():
+            if self.transposed:      # [Cin, Cout, k, k] -> [(di k + dj) Cout + co][ci]
+                wl = w.permute(2, 3, 1, 0).reshape(self._n, self.in_features)
+                bl = None if b is None else b.repeat(self.k * self.k)
+            else:                    # [Cout, Cin, 1, 1]
+                wl = w.reshape(self._n, self.in_features)
+                bl = b
+            if self.out_features != self._n:
+                wl = torch.cat([wl, wl.new_zeros(self.out_features - self._n, self.in_features)])
+                bl = None if bl is None else torch.cat([bl, bl.new_zeros(self.out_features - self._n)])
+            self.weight = wl.contiguous()
+            self.bias = None if bl is None else bl.contiguous()
+        self._key = key
+
+    def __call__(self, x: torch.Tensor, h: int, w: int, act: int = 0, precision: str = "fp32") -> torch.Tensor:
+        """x [B, h*w, Cin] token-major -> [B, (h k)*(w k), Cout] token-major."""
+        self.refresh()
+        b = x.shape[0]
+        y = linear(x, self, act=act, precision=precision)
+        if self.out_features != self._n:
+            y = y[..., :self._n]
+        if self.transposed and self.k > 1:
+            k = self.k
+            y = y.reshape(b, h, w, k, k, self.cout).permute(0, 1, 3, 2, 4, 5).reshape(b, h * k * w * k, self.cout)
+        return y.contiguous()
 
 
 def attention_block_linears_supported(dim: int, hidden: int) -> bool:

@@ -152,3 +152,45 @@ def test_block_linear_forms_hold_the_reference_bound(tag):
     model.set_linear_form("bf16")
     got = model(constants=dev(constants), prescribed=dev(prescribed), prognostic=dev(prognostic))
     assert max(per_step_rel_l2(got, want)) <= 5e-3
+
+
+@pytest.mark.parametrize("kind,cin,cout,k", [("convT", 192, 96, 2), ("convT", 96, 48, 1), ("convT", 64, 32, 4), ("conv", 96, 3, 1),
+                                             ("conv", 64, 8, 1)])
+def test_conv_as_linear_matches_torch_convolution(kind, cin, cout, k):
+    """ops.ConvAsLinear (the Swin decoder's kernel = stride transposed convolutions and its 1x1 head as Linears over
+    token-major data, swin_transformer.py:600-612) against torch's convolution in float64, GELU fused."""
+    from dlwp_benchmark_amd import ops
+
+    torch.manual_seed(cin + cout + k)
+    conv = (torch.nn.ConvTranspose2d(cin, cout, k, k) if kind == "convT" else torch.nn.Conv2d(cin, cout, 1)).to(DEV)
+    b, h, w = 2, 6, 10
+    x = torch.randn(b, cin, h, w, device=DEV)
+    lin = ops.ConvAsLinear(conv)
+    with torch.no_grad():
+        tok = x.permute(0, 2, 3, 1).reshape(b, h * w, cin).contiguous()
+        got = lin(tok, h, w, act=1)
+        want = F.gelu(conv.double()(x.double()))
+        kk = k if kind == "convT" else 1
+        want_tok = want.permute(0, 2, 3, 1).reshape(b, h * kk * w * kk, cout)
+    assert got.shape == want_tok.shape
+    assert rel_l2(got, want_tok) <= 1e-6
+    # the derived weight follows the module's parameters
+    with torch.no_grad():
+        conv.float()
+        conv.weight.mul_(0.5)
+        got2 = lin(tok, h, w, act=0)
+        want2 = conv.double()(x.double()).permute(0, 2, 3, 1).reshape(b, h * kk * w * kk, cout)
+    assert rel_l2(got2, want2) <= 1e-6
+
+
+@pytest.mark.parametrize("cin,c", [(8, 96), (18, 192), (5, 64), (3, 20)])
+def test_patch_embed_1x1_any_multiple_of_four(cin, c):
+    from dlwp_benchmark_amd import ops
+
+    torch.manual_seed(cin * c)
+    conv = torch.nn.Conv2d(cin, c, 1).to(DEV)
+    x = torch.randn(3, cin, 7, 9, device=DEV)
+    with torch.no_grad():
+        got = ops.patch_embed_1x1(x, conv.weight, conv.bias, None)
+        want = conv.double()(x.double()).flatten(2).transpose(1, 2)
+    assert got.shape == want.shape and rel_l2(got, want) <= 1e-6
