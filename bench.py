@@ -200,6 +200,12 @@ def bench_other_configs(device, only=None, reps=2):
         model = getattr(M, cls)(**cfg)
         sha = fill_state_dict(model, gain=gain)
         model = model.to(device).eval()
+        # DLWP_BENCH_STEP_GRAPHS=all|unet: replay one_step as a HIP graph (HipBackbone.set_step_graphs).  Measured in round 2:
+        # no gain on any config (C1 0.61 vs 0.58 ms, C3 / C4 / C5 within noise) -- none of them is bound by the host's launch
+        # rate -- so the default stays eager.
+        gsel = os.environ.get("DLWP_BENCH_STEP_GRAPHS", "none")
+        graphs_on = gsel == "all" or (gsel == "unet" and cls == "UNet")
+        model.set_step_graphs(graphs_on)
         if cfg["constant_channels"] == 0:
             c, p, g = navier_stokes(batch, steps + 1, h, w, channels=cfg["prognostic_channels"])
         else:
@@ -220,7 +226,8 @@ def bench_other_configs(device, only=None, reps=2):
             what = {"fp32": "fp32", "bf16": "bf16 window attention (fp32 elsewhere)",
                     "bf16all": "bf16 window attention and bf16 Linear operands (fp32 accumulation, LayerNorm, residual stream)"}[variant]
             entry = {"workload": f"{cls} {h}x{w}, {cfg['prognostic_channels']} prognostic ch, {steps}-step rollout, {what}",
-                     "batch": batch, "rollout_steps": steps, "weights": "deterministic filler sha256:" + sha[:16]}
+                     "batch": batch, "rollout_steps": steps, "weights": "deterministic filler sha256:" + sha[:16],
+                     "launch": "one_step replayed as a HIP graph (set_step_graphs)" if graphs_on else "eager launches"}
             out = model(constants=c, prescribed=p, prognostic=g)      # warm-up (plans, allocator)
             torch.cuda.synchronize()
             times = []
@@ -244,9 +251,11 @@ def bench_other_configs(device, only=None, reps=2):
                 entry["golden"] = f"tests/golden/model_{gold}.npz (real reference class, {want.shape[0]} sample, {want.shape[1]} steps)"
                 entry["rel_l2_bound"] = 5e-3 if prec == "bf16" else 1e-5
                 entry["parity_ok"] = max(errs) <= entry["rel_l2_bound"]
-            # per-entry-point event timing of one more rollout
+            # per-entry-point event timing of one more rollout (eager: events cannot bracket the nodes of a graph)
+            model.set_step_graphs(False)
             with L.KernelTimer(tagger=_attn_tag) as kt:
                 model(constants=c, prescribed=p, prognostic=g)
+            model.set_step_graphs(graphs_on)
             summ, marker = kt.summary()
             covered = sum(v["total_ms"] for v in summ.values())
             by_name = {}
