@@ -31,6 +31,7 @@
 //   * LDS rows are 64 bytes (32 bf16), unpadded, with the 16-byte chunks XOR-swizzled by f(row) = (4 - (row & 15) / 4) & 3:
 //     the ds_read_b128 operand reads (lane groups {0-3, 12-15, 20-27}, ...) are conflict free (SQ_LDS_BANK_CONFLICT = 0).
 #include "common.hpp"
+#include <atomic>
 #include <type_traits>
 
 namespace dlwp {
@@ -324,17 +325,23 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restric
 
 template <int BN, int NP>
 static int32_t launch_v2(const Params& p, hipStream_t s) {
-  static int slots = 0;      // resident workgroups on the device (2 per CU by LDS), found once
+  // resident workgroups (2 per CU by LDS) of the CURRENT device, found once per device: hipFuncSetAttribute is per device too.
+  // (atomic: concurrent first calls race benignly to the same value)
+  static std::atomic<int> slots_of[64];
   constexpr size_t lds = (size_t)NP * 8192 + 2 * (size_t)NP * BN * 64;
   auto kern = linear_kernel<BN, NP>;
+  int dev = 0;
+  DLWP_HIP_CHECK(hipGetDevice(&dev));
+  DLWP_REQUIRE(dev >= 0 && dev < 64, DLWP_ERR_UNSUPPORTED, "linear: device ordinal %d", dev);
+  int slots = slots_of[dev].load(std::memory_order_relaxed);
   if (!slots) {
     DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0, cus = 0, per_cu = 0;
-    DLWP_HIP_CHECK(hipGetDevice(&dev));
+    int cus = 0, per_cu = 0;
     DLWP_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     DLWP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
     DLWP_REQUIRE(per_cu > 0 && cus >= 8, DLWP_ERR_UNSUPPORTED, "linear: kernel does not fit on this device");
     slots = cus * per_cu;
+    slots_of[dev].store(slots, std::memory_order_relaxed);
   }
   const long long tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   long long per_xcd = ((tiles_m + 7) / 8) * tiles_n;      // the busiest XCD's tile count
