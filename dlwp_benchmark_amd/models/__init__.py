@@ -11,7 +11,8 @@ from .fourcastnet import AFNONet, FourCastNet
 from .pangu import PanguWeather
 from .spectral import SpectralConv2d
 from .swin import SwinTransformer, SwinTransformerHPX
+from .diffusion import DiffModernUNet, DiffMUNetHPX
 from .unet import ConvLSTM, ConvLSTMHPX, HEALPixLayer, HEALPixPadding, ModernUNet, MUNetHPX, UNet, UNetHPX
 
-__all__ = ["FNO2DModule", "TFNO2DModule", "ConvLSTMHPX", "ModernUNet", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "SwinTransformerHPX", "UNet",
+__all__ = ["DiffModernUNet", "DiffMUNetHPX", "FNO2DModule", "TFNO2DModule", "ConvLSTMHPX", "ModernUNet", "FourCastNet", "AFNONet", "PanguWeather", "SpectralConv2d", "SwinTransformer", "SwinTransformerHPX", "UNet",
            "UNetHPX", "MUNetHPX", "ConvLSTM", "HEALPixPadding", "HEALPixLayer"]

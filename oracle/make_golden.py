@@ -370,6 +370,57 @@ def gen_hpx(ref):
               state_spec=np.array(json.dumps(full)))
 
 
+DIFFUSION_CASES = {
+    # (class, ctor kwargs, (batch, frames), (H, W) [faces implied for HPX], betas, inference steps)
+    "diffmunet_h16_8_norm": ("DiffModernUNet", dict(constant_channels=2, prescribed_channels=1, prognostic_channels=3,
+                                                    hidden_channels=[16, 8], context_size=2, norm=True, use_scale_shift_norm=True,
+                                                    num_refinement_step=3, activation="th.nn.GELU()"), (2, 4), (16, 32),
+                             [0.5, 0.3, 0.1, 0.05], 3),
+    "diffmunet_h8_16_bias": ("DiffModernUNet", dict(constant_channels=0, prescribed_channels=0, prognostic_channels=2,
+                                                    hidden_channels=[8, 16], context_size=1, norm=False, use_scale_shift_norm=False,
+                                                    num_refinement_step=2), (1, 3), (8, 16), [0.4, 0.2, 0.1], 2),
+    "diffmunethpx_h8_16": ("DiffMUNetHPX", dict(constant_channels=1, prescribed_channels=1, prognostic_channels=2,
+                                                hidden_channels=[8, 16], context_size=1, norm=True, num_refinement_step=2),
+                           (1, 3), (8, 8), [0.4, 0.2, 0.1], 2),
+}
+DIFFUSION_SEED = 2024          # torch.manual_seed before the forward: the start noise comes from the host's global generator
+
+
+def diffusion_inputs(tag, cls, cfg, batch, frames, hw):
+    h, w = hw
+    face = (12,) if cls.endswith("HPX") else ()
+    cc, cp, cg = cfg["constant_channels"], cfg["prescribed_channels"], cfg["prognostic_channels"]
+    constants = W.normal(f"golden/diff/{tag}/constants", (batch, 1, cc) + face + (h, w), 1.0) if cc else None
+    prescribed = W.normal(f"golden/diff/{tag}/prescribed", (batch, frames, cp) + face + (h, w), 1.0) if cp else None
+    prognostic = W.normal(f"golden/diff/{tag}/prognostic", (batch, frames, cg) + face + (h, w), 1.0)
+    return constants, prescribed, prognostic
+
+
+def gen_diffusion():
+    """PDE-Refiner backbones: the REAL reference classes driven by the restated DDPM scheduler."""
+    import contextlib
+    import io
+    import json
+
+    from oracle.restate.ddpm import DDPMSchedulerRestated
+
+    mod = ref_import.load_reference_diffusion()
+    for tag, (cls, cfg, (batch, frames), hw, betas, nsteps) in DIFFUSION_CASES.items():
+        m = getattr(mod, cls)(**cfg)
+        m.eval()
+        sha = W.fill_state_dict(m, gain=0.7)      # the reference zero-initialises conv2 / output_layer: fill everything
+        constants, prescribed, prognostic = diffusion_inputs(tag, cls, cfg, batch, frames, hw)
+        sched = DDPMSchedulerRestated(betas, seed=7)
+        sched.set_timesteps(nsteps)
+        torch.manual_seed(DIFFUSION_SEED)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):   # the reference forward prints its progress
+            y = m(constants=constants, prescribed=prescribed, prognostic=prognostic, noise_scheduler=sched, target=None)
+        spec = [(k, list(v.shape)) for k, v in m.named_parameters()]
+        full = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()]
+        _save(f"model_{tag}", y=y.numpy().astype(np.float32), sha=np.array(sha), param_spec=np.array(json.dumps(spec)),
+              state_spec=np.array(json.dumps(full)))
+
+
 def main():
     if not ref_import.reference_available():
         raise SystemExit("reference tree not available: golden fixtures can only be regenerated in the build container")
@@ -380,7 +431,9 @@ def main():
         gen_spectral(ref)
     if not only or "hpx" in only:
         gen_hpx(ref)
-    rest = only - {"spectral", "hpx", "grads", "horizons"} - set(HORIZON_CASES)
+    if not only or "diffusion" in only:
+        gen_diffusion()
+    rest = only - {"spectral", "hpx", "grads", "horizons", "diffusion"} - set(HORIZON_CASES)
     if not only or "grads" in only:
         gen_grads(ref, None)
     if not only or rest:

@@ -145,6 +145,24 @@ def load_reference():
     return out
 
 
+def load_reference_diffusion():
+    """models/diffusion_models/modern_unet/modern_unet.py (DiffModernUNet, DiffMUNetHPX).  AS SHIPPED the module cannot be
+    imported: its line 4 asks `utils` for `ConditionalHEALPixLayer`, which utils/__init__.py does not export (the class exists,
+    utils/healpix.py:117).  The oracle re-exports the reference's OWN class on the in-memory `utils` module -- no arithmetic is
+    replaced -- and imports the file unchanged."""
+    import importlib
+
+    ref = load_reference()
+    ref["utils"].ConditionalHEALPixLayer = importlib.import_module("utils.healpix").ConditionalHEALPixLayer
+    for sub in ("diffusion_models", "diffusion_models.modern_unet"):
+        name = f"models.{sub}"
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REF_PKG, "models", *sub.split("."))]
+            sys.modules[name] = m
+    return importlib.import_module("models.diffusion_models.modern_unet.modern_unet")
+
+
 if __name__ == "__main__":
     mods = load_reference()
     for k, v in mods.items():

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_CFG = "/root/reference/src/dlwpbench/configs/model"
 
 HOT_PATH_TYPES = {"FourCastNet", "PanguWeather", "SwinTransformer", "SwinTransformerHPX", "UNet", "UNetHPX", "ModernUNet",
-                  "MUNetHPX", "FNO2DModule", "TFNO2DModule", "ConvLSTM", "ConvLSTMHPX"}        # SURVEY.md 8b "Registry"
+                  "MUNetHPX", "FNO2DModule", "TFNO2DModule", "ConvLSTM", "ConvLSTMHPX",           # SURVEY.md 8b "Registry"
+                  "DiffModernUNet", "DiffMUNetHPX"}                                               # 8f row f4 (models/__init__.py:15)
 INTERP = {"${data.height}": 32, "${data.width}": 64, "${training.batch_size}": 4, "${device}": "cpu"}
 
 
