@@ -559,7 +559,8 @@ static int32_t launch3(const Geo& G, bool mask, const float* qkv, const float* q
   const size_t lds = lds_bytes<RP, PP, PB, NP>(G);
   if (lds > 160 * 1024) return 1;
   const long long gy = (long long)batch * G.npl * G.nlat * (RP + PP) * G.nch;
-  DLWP_REQUIRE(gy < 65536, DLWP_ERR_UNSUPPORTED, "window attention: batch x window rows = %lld exceeds the grid", gy);
+  const long long gy2 = (long long)batch * G.npl * (RP + PP) * G.ncut;
+  if (gy >= 65536 || gy2 >= 65536) return 1;      // beyond the grid's y extent: the generic kernel takes the call
   const dim3 grid((unsigned)G.heads, (unsigned)gy), block(64 * PB);
   auto go = [&](auto kern, dim3 gr) -> int32_t {
     if (lds > 48 * 1024)
@@ -572,8 +573,6 @@ static int32_t launch3(const Geo& G, bool mask, const float* qkv, const float* q
   int32_t rc = go(wattn3_kernel<RP, PP, PB, NP, 1>, grid);
   if (rc != DLWP_OK) return rc;
   if (mask && G.ncut > 0) {
-    const long long gy2 = (long long)batch * G.npl * (RP + PP) * G.ncut;
-    DLWP_REQUIRE(gy2 < 65536, DLWP_ERR_UNSUPPORTED, "window attention: %lld cut windows exceed the grid", gy2);
     rc = go(wattn3_kernel<RP, PP, PB, NP, 2>, dim3((unsigned)G.heads, (unsigned)gy2));
     if (rc != DLWP_OK) return rc;
   }
