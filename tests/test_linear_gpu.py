@@ -194,3 +194,33 @@ def test_patch_embed_1x1_any_multiple_of_four(cin, c):
         got = ops.patch_embed_1x1(x, conv.weight, conv.bias, None)
         want = conv.double()(x.double()).flatten(2).transpose(1, 2)
     assert got.shape == want.shape and rel_l2(got, want) <= 1e-6
+
+
+def test_linear_random_shape_sweep():
+    """Random (rows, in, out) triples, every epilogue combination: the persistent tile walk (XCD-owned slabs, chunked n-tiles,
+    clamped tails) must cover every output exactly once."""
+    import random
+
+    from dlwp_benchmark_amd import ops
+
+    rng = random.Random(1234)
+    for trial in range(24):
+        rows = rng.choice([1, 7, 127, 128, 129, 640, 1023, 1025, 3000, 5000, 8191, 20000])
+        k = 32 * rng.randint(1, 24)
+        n = 4 * rng.randint(1, 200)
+        act, has_res, has_bias = rng.randint(0, 1), rng.random() < 0.5, rng.random() < 0.7
+        prec = "bf16" if trial % 4 == 3 else "fp32"
+        m = _linear(k, n, has_bias, seed=trial)
+        g = torch.Generator().manual_seed(trial)
+        x = torch.randn(rows, k, generator=g).to(DEV)
+        r = torch.randn(rows, n, generator=g).to(DEV) if has_res else None
+        with torch.no_grad():
+            got = ops.linear(x, m, act=act, resid=r, precision=prec)
+            xe, we = (x.bfloat16().double(), m.weight.bfloat16().double()) if prec == "bf16" else (x.double(), m.weight.double())
+            want = F.linear(xe, we, m.bias.double() if has_bias else None)
+            if act:
+                want = F.gelu(want)
+            if has_res:
+                want = want + r.double()
+        assert torch.isfinite(got).all(), (trial, rows, k, n)
+        assert rel_l2(got, want) <= 1e-6, (trial, rows, k, n, act, has_res, has_bias, prec, rel_l2(got, want))
