@@ -438,7 +438,9 @@ def main():
     # graph and replayed per step (launch gaps between the dependent nodes: ~1.5 us instead of ~6 us each).  Only without
     # a collective inside the step (--collect gather issues RCCL calls per chunk) and with the deferred verification
     # (a captured call cannot synchronise).  DLWP_BENCH_GRAPH=0 runs the same step eagerly.
-    use_graph = args.collect != "gather" and os.environ.get("DLWP_BENCH_GRAPH", "1") != "0"
+    # Default OFF: measured 2.006 (graph) vs 2.003 ms (eager) per step -- what is left beside the kernel is GPU work, not launch
+    # gaps -- and a capture beside a live RCCL communicator (N > 1) is one more thing that can go wrong for no gain.
+    use_graph = args.collect != "gather" and world == 1 and os.environ.get("DLWP_BENCH_GRAPH", "0") == "1"
     graph = {"g": None, "out": None}
 
     def step():
