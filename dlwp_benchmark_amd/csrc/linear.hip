@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
     x_store(px);
     if (advance(cx)) x_rows(cx);
     x_issue(px, cx);                         // x(t+2), into the registers just split
+    __builtin_amdgcn_s_setprio(1);           // matrix phase first: the other resident workgroup's vector phases fill its gaps (2-7 % measured)
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       if (b > 0) {
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
         for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_bf16(wa[0], xb[a][0], acc[a][b]);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // W(t+1) has landed when at most the 4 x loads issued behind it are outstanding
     if (cc.ks == nk - 1) {
       if (p.resid) epilogue(std::true_type{}); else epilogue(std::false_type{});
