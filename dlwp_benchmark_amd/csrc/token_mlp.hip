@@ -333,6 +333,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
         a1[tt][0] = bb;
         a1[tt][1] = bb;
       }
+      __builtin_amdgcn_s_setprio(1);     // matrix bursts first: the SIMD's other wave fills their gaps with its GELU / splits
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         u32x4 wa[2][3];
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
             for (int q = 0; q < 2; ++q)
               a1[tt][q] = mfma16x16x32_bf16(wa[tt][kPA[term]], bx[q][ks][kPB[term]], a1[tt][q]);
       }
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       load_lo1(un);
       // ---- GELU, then the 3-way split straight into layer-2 B operands
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
           bg[q][2][i] = ll;
         }
       // ---- layer 2: out tiles two at a time
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int oh = 0; oh < OT; oh += 2) {
         u32x4 wb[2][3];
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
             for (int q = 0; q < 2; ++q)
               acc2[oh + oo][q] = mfma16x16x32_bf16(wb[oo][kPA[term]], bg[q][kPB[term]], acc2[oh + oo][q]);
       }
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       load_lo2(un);
     };
