@@ -205,8 +205,12 @@ static void launch_conv3x3_co(const conv::Params& p, hipStream_t s) {
 static void launch_conv3x3(const conv::Params& p, hipStream_t s) {
   const int th = p.W >= 32 ? 8 : (p.W >= 16 ? 16 : 8), tw = p.W >= 32 ? 32 : (p.W >= 16 ? 16 : 8);
   const long long wgs16 = (long long)((p.W + tw - 1) / tw) * ((p.H + th - 1) / th) * p.B * ((p.Cout + 15) / 16);
+  // waves in flight with 4 output channels per thread: below ~8 per CU a layer is a chain of exposed load latencies (the 8 x 8
+  // and 16 x 16 levels of a U-Net at B = 32: 512 / 1024 waves on 256 CUs) -- one channel per thread quadruples the workgroups
+  const long long waves4 = (long long)((p.W + tw - 1) / tw) * ((p.H + th - 1) / th) * p.B * ((p.Cout + 3) / 4) * (th * tw / 64);
   if (wgs16 >= 1024) launch_conv3x3_co<16>(p, s);
-  else launch_conv3x3_co<4>(p, s);
+  else if (waves4 >= 2048) launch_conv3x3_co<4>(p, s);
+  else launch_conv3x3_co<1>(p, s);
 }
 
 extern "C" int32_t dlwp_conv3x3_ex_f32(const float* x0, int32_t c0, const float* x1, int32_t c1, const float* weight,
