@@ -318,6 +318,8 @@ struct Shape {
     static constexpr bool ok = true;                                                \
     static constexpr int AR = AR_, BR = BR_, AC = AC_, BC = BC_, NT = NT_;          \
     static constexpr int NTI = NT_ > 512 ? 512 : NT_;   /* inverse: 512 threads (256 VGPRs) -- 1024 spilled */ \
+    /* inverse with at most half the columns kept (a smaller register prefetch): 768 threads, 12 waves to cover the barriers */ \
+    static constexpr int NTIH = NT_ > 512 ? 768 : NT_; \
   };
 // (H, W) -> row FFT of W/2 = AR * BR, column FFT of H = AC * BC, threads per workgroup
 DLWP_AFFT_SHAPE(128, 256, 8, 16, 16, 8, 1024)
@@ -355,11 +357,12 @@ int32_t run_shape(const dlwp_afno_fft_plan* p, const float* x, float* spec, floa
   } else {
     // two instantiations by how many columns are kept: the next plane's spectrum is prefetched into registers
     constexpr int KHALF = NR / 2 + 1;
-    auto kern = p->KC <= KHALF ? afft::afno_irfft2_kept_kernel<H, W, S::AR, S::BR, S::AC, S::BC, S::NTI, KHALF>
-                               : afft::afno_irfft2_kept_kernel<H, W, S::AR, S::BR, S::AC, S::BC, S::NTI, NR + 1>;
+    const bool half = p->KC <= KHALF;
+    auto kern = half ? afft::afno_irfft2_kept_kernel<H, W, S::AR, S::BR, S::AC, S::BC, S::NTIH, KHALF>
+                     : afft::afno_irfft2_kept_kernel<H, W, S::AR, S::BR, S::AC, S::BC, S::NTI, NR + 1>;
     if (lds > 48 * 1024)
       DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(S::NTI), lds, s, reinterpret_cast<const float2*>(spec), y, T, p->KC, planes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(half ? S::NTIH : S::NTI), lds, s, reinterpret_cast<const float2*>(spec), y, T, p->KC, planes);
   }
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
