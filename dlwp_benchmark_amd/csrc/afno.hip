@@ -117,9 +117,8 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
   // every 16-column tile of every row is visited: kept points are mixed, the rest of the row (columns >= km) and the
   // rows outside [row_lo, row_hi) are written as zeros by the same pass -- whole rows leave the kernel contiguously
   // (the separate zero-fill launch + the half-row writes of the first version: 103 + 47 us per call at C4)
-  const int kt = (p.Wf + 15) / 16;                       // 16-point tiles per spectrum row
-  const int nrows = p.H;
-  const long long ntiles = (long long)p.B * nrows * kt;
+  const int kt = (int)((plane + 15) / 16);               // 16-point tiles per spectrum plane
+  const long long ntiles = (long long)p.B * kt;
   // wave w of the workgroup owns channel block w (w + 4, ...): its weights are gathered into registers ONCE and
   // reused for every 16-point tile the workgroup visits
   const int wave = threadIdx.x >> 6;
@@ -153,16 +152,42 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
       bias1[nt] = f32x4{bb1[0], bb1[1], bb1[2], bb1[3]};
       bias2[nt] = f32x4{bb2[0], bb2[1], bb2[2], bb2[3]};
     }
-    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // tile geometry + the tile's inputs; the NEXT tile's inputs are requested before the current tile's 32 matrix
+    // instructions (a wave otherwise alternates between waiting for 512 bytes and computing on them)
+    struct Tile { long long base; bool kept, live, in_row; };
+    auto geom = [&](long long t) {
+      // a tile = 16 CONSECUTIVE points of the flattened [H][Wf] plane: 128 aligned bytes per channel whatever Wf is (tiles
+      // cut along rows put every access of a 65-column spectrum across two cache lines)
+      Tile q;
       const int tile = (int)(t % kt);
-      const int h = (int)((t / kt) % nrows);
-      const int b = (int)(t / ((long long)kt * nrows));
-      const int col = tile * 16 + j;
-      const bool kept_tile = h >= p.row_lo && h < p.row_hi && tile * 16 < p.km;   // wave-uniform
-      const bool live = kept_tile && col < p.km;
-      const bool in_row = col < p.Wf;
-      const long long base = (long long)b * p.C * plane + (long long)h * p.Wf + (in_row ? col : 0);
-      if (!kept_tile) {
+      const int b = (int)(t / kt);
+      const int pt = tile * 16 + j;
+      const int h = pt / p.Wf, col = pt - h * p.Wf;
+      q.in_row = pt < (int)plane;
+      q.live = q.in_row && h >= p.row_lo && h < p.row_hi && col < p.km;
+      q.kept = __any(q.live);                                       // wave-uniform
+      q.base = (long long)b * p.C * plane + (q.in_row ? pt : 0);
+      return q;
+    };
+    auto fetch = [&](const Tile& q, float2 (&v)[4]) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = q.live ? p.x[q.base + (long long)(blk * BS + 4 * s + g) * plane] : float2{0.f, 0.f};
+    };
+    float2 xnext[4];
+    Tile qn = geom(blockIdx.x < ntiles ? blockIdx.x : 0);
+    if (blockIdx.x < ntiles) fetch(qn, xnext);
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const Tile q = qn;
+      const long long base = q.base;
+      const bool live = q.live, in_row = q.in_row;
+      float2 xin[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xin[s] = xnext[s];
+      if (t + gridDim.x < ntiles) {
+        qn = geom(t + gridDim.x);
+        fetch(qn, xnext);
+      }
+      if (!q.kept) {
         if (in_row) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) p.y[base + (long long)(blk * BS + 4 * g + r) * plane] = float2{0.f, 0.f};
@@ -170,10 +195,8 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
         continue;
       }
       // ---- layer 1
-      float2 xin[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        xin[s] = live ? p.x[base + (long long)(blk * BS + 4 * s + g) * plane] : float2{0.f, 0.f};
         xin[s].x *= p.in_scale;
         xin[s].y *= p.in_scale;
       }
@@ -242,7 +265,7 @@ extern "C" int32_t dlwp_afno2d_mix_scaled_f32(const float* xf, float* yf, const 
     case 8: hipLaunchKernelGGL(afno::afno_mix_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
     case 16: {
       // MFMA form: kept points on the matrix lanes, zeros elsewhere from the same pass
-      const long long tiles = (long long)batch * H * ((Wf + 15) / 16);
+      const long long tiles = (long long)batch * (((long long)H * Wf + 15) / 16);
       long long wg = tiles;
       if (wg > 256 * 8) wg = 256 * 8;
       hipLaunchKernelGGL(afno::afno_mix_mfma16_kernel, dim3((unsigned)(wg > 0 ? wg : 1)), dim3(256), 0, s, p);
