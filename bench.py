@@ -52,6 +52,8 @@ def build_model(device):
     m = FNO2DModule(**MODEL_KW)
     sha = fill_state_dict(m, std_fn=std_fn, gain=0.85)
     m.set_execution_form(check="deferred")      # asynchronous rollouts, verified by model.verify() in finish()
+    if os.environ.get("DLWP_BENCH_PRECISION"):  # A/B of the product forms (default: the module's, "f16x3")
+        m.set_execution_form(precision_form=os.environ["DLWP_BENCH_PRECISION"])
     return m.to(device).eval(), sha
 
 
@@ -519,6 +521,11 @@ def main():
                                                           "none": "no collective"}[args.collect])
             if world > 1 else "single GPU",
             "collect": args.collect,
+            "precision_form": {"f16x3": "f16x3: fp32 accumulation; the big channel products from exact two-part f16 splits of fp32 operands "
+                                        "(22 significant bits, three f16 matrix instructions per product; DLWP_BENCH_PRECISION=bf16x6 selects "
+                                        "the three-part bf16 form)",
+                               "bf16x6": "bf16x6: fp32 accumulation; products from exact three-part bf16 splits (six bf16 matrix instructions)",
+                               "fp32_mfma": "plain fp32 matrix instructions, unfused"}[model.precision_form],
             "fused_kernel_check": "deferred: rollouts enqueued asynchronously, verified once per evaluation inside the timed region",
             "launch": "hip graph replay of one step (memsets + rollout kernel + metric sums)" if graph["g"] is not None else "eager",
             "weights": "deterministic filler sha256:" + sha[:16],

@@ -124,36 +124,54 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
   const float x0 = u[0], x1 = u[1], x2 = u[2], x3 = u[3], x4 = v[0], x5 = v[1], x6 = v[2], x7 = v[3];
   float t0, t1, t2, t3, t4, t5, t6, t7;
-  const float umax = DLWP_GELU_UMAX;
+  // The clamp constant sits in an SGPR the compiler cannot see through: with a literal it emits v_max |x|,|x| + v_min
+  // (a VOP3 instruction, which the |x| modifier needs, takes no literal on gfx9) -- one wasted issue slot per element.
+  float umax = DLWP_GELU_UMAX;
+  asm volatile("" : "+s"(umax));
   // The FIRST reads of the inputs are plain C, not asm: the inputs are often MFMA results, and a VALU read of a
   // register an MFMA has just written needs several wait states that hipcc only inserts for instructions it can see --
   // its hazard recognizer skips inline asm (a fused kernel whose schedule put `v_mfma ... v[64:67]` directly in front
   // of an asm `v_min_f32 v100, |v64|` computed garbage for exactly those elements).
-  t0 = fminf(fabsf(x0), umax); t2 = fminf(fabsf(x2), umax); t4 = fminf(fabsf(x4), umax); t6 = fminf(fabsf(x6), umax);
-  t1 = fminf(fabsf(x1), umax); t3 = fminf(fabsf(x3), umax); t5 = fminf(fabsf(x5), umax); t7 = fminf(fabsf(x7), umax);
+  // (v_med3_f32 |x|, 0, umax = min(|x|, umax) in ONE instruction: fminf(fabsf(x), c) costs two, because IEEE mode makes
+  // hipcc canonicalize the operand of a minimum with v_max |x|, |x| first)
+#define DLWP_CLAMP(x) __builtin_amdgcn_fmed3f(__builtin_fabsf(x), 0.f, umax)
+  t0 = DLWP_CLAMP(x0); t2 = DLWP_CLAMP(x2); t4 = DLWP_CLAMP(x4); t6 = DLWP_CLAMP(x6);
+  t1 = DLWP_CLAMP(x1); t3 = DLWP_CLAMP(x3); t5 = DLWP_CLAMP(x5); t7 = DLWP_CLAMP(x7);
+#undef DLWP_CLAMP
   const f32x2 ta = {t0, t1}, tb = {t2, t3}, tc = {t4, t5}, td = {t6, t7};
   f32x2 pa = {DLWP_GELU_QTOP, DLWP_GELU_QTOP}, pb = pa, pc = pa, pd = pa;
-#define DLWP_PKSTEP4(cf)                                                                       \
+  float m0, m1, m2, m3, m4, m5, m6, m7;
+#define DLWP_X(m, x) asm volatile("v_max_f32_e32 %0, 0, %1" : "=v"(m) : "v"(x));
+  // A dependent v_pk_fma_f32 needs FOUR other instructions behind its producer (hipcc pads a group of four chains with
+  // an s_nop, a full issue slot): the max(x, 0) of the final combination fill those slots instead.
+#define DLWP_PKSTEP4(cf, FILL)                                                                 \
   {                                                                                            \
     const f32x2 cc = {cf, cf};                                                                 \
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pa) : "v"(pa), "v"(ta), "s"(cc));        \
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pb) : "v"(pb), "v"(tb), "s"(cc));        \
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pc) : "v"(pc), "v"(tc), "s"(cc));        \
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pd) : "v"(pd), "v"(td), "s"(cc));        \
+    FILL                                                                                       \
   }
-  DLWP_GELU_COEFFS(DLWP_PKSTEP4)
-  DLWP_PKSTEP4(-1.0f)   // exponent u Q(u) - 1
+#define DLWP_C5(c0, c1, c2, c3, c4)                                                            \
+  DLWP_PKSTEP4(c0, DLWP_X(m0, x0)) DLWP_PKSTEP4(c1, DLWP_X(m1, x1)) DLWP_PKSTEP4(c2, DLWP_X(m2, x2))     \
+  DLWP_PKSTEP4(c3, DLWP_X(m3, x3)) DLWP_PKSTEP4(c4, DLWP_X(m4, x4))
+#define DLWP_CX(c) c,
+#define DLWP_C5_APPLY(...) DLWP_C5_EXPAND(__VA_ARGS__)
+#define DLWP_C5_EXPAND(c0, c1, c2, c3, c4, ...) DLWP_C5(c0, c1, c2, c3, c4)
+  DLWP_C5_APPLY(DLWP_GELU_COEFFS(DLWP_CX) 0)
+#undef DLWP_C5_APPLY
+#undef DLWP_C5_EXPAND
+#undef DLWP_CX
+#undef DLWP_C5
+  DLWP_PKSTEP4(-1.0f, DLWP_X(m5, x5) DLWP_X(m6, x6) DLWP_X(m7, x7))   // exponent u Q(u) - 1
 #undef DLWP_PKSTEP4
-  float m0, m1, m2, m3, m4, m5, m6, m7;
-#define DLWP_X(m, x) asm volatile("v_max_f32_e32 %0, 0, %1" : "=v"(m) : "v"(x));
-  DLWP_X(m0, x0) DLWP_X(m1, x1) DLWP_X(m2, x2) DLWP_X(m3, x3)
+#undef DLWP_X
   float e0, e1, e2, e3, e4, e5, e6, e7;
   const float a0 = pa.x, a1 = pa.y, a2 = pb.x, a3 = pb.y, a4 = pc.x, a5 = pc.y, a6 = pd.x, a7 = pd.y;
 #define DLWP_E(e, a) asm volatile("v_exp_f32_e32 %0, %1" : "=v"(e) : "v"(a));
   DLWP_E(e0, a0) DLWP_E(e1, a1) DLWP_E(e2, a2) DLWP_E(e3, a3) DLWP_E(e4, a4) DLWP_E(e5, a5) DLWP_E(e6, a6) DLWP_E(e7, a7)
 #undef DLWP_E
-  DLWP_X(m4, x4) DLWP_X(m5, x5) DLWP_X(m6, x6) DLWP_X(m7, x7)
-#undef DLWP_X
   float r0, r1, r2, r3, r4, r5, r6, r7;
 #define DLWP_F(r, x, h, m) asm volatile("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(r) : "v"(x), "v"(h), "v"(m));
   DLWP_F(r0, x0, e0, m0) DLWP_F(r1, x1, e1, m1) DLWP_F(r2, x2, e2, m2) DLWP_F(r3, x3, e3, m3)
@@ -202,6 +220,16 @@ __device__ __forceinline__ void gelu_erf8_fma(f32x4& u, f32x4& v) {
   v = f32x4{r4, r5, r6, r7};
 }
 
+// TIMING EXPERIMENTS ONLY (tools/ab_build.sh, never in the shipped library): a GELU that costs one instruction per
+// element, and (-DDLWP_KO_SPLIT) a "split" that keeps only the leading bf16 part with a single MFMA per product.
+__device__ __forceinline__ void gelu_ko8(f32x4& u, f32x4& v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u[i] = fmaxf(u[i], 0.f);
+    v[i] = fmaxf(v[i], 0.f);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 GEMM on the bf16 matrix pipe ("bf16x6")
 //   x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (exact to 2^-24 |x|)
@@ -229,6 +257,11 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // RNE, a i
 // three-way bf16 split of a pair of floats: 9 VALU issue slots (3 cvt_pk, 4 unpack, 2 packed subtract)
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
   h = cvt_pk_bf16(x0, x1);
+#ifdef DLWP_KO_SPLIT
+  m = h;
+  l = h;
+  return;
+#endif
   const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
   m = cvt_pk_bf16(r0, r1);
   const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
@@ -237,6 +270,9 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 
 // D += A*B with A = (ah, am, al), B = (bh, bm, bl), smallest terms first
 __device__ __forceinline__ f32x4 mfma_bf16x6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+#ifdef DLWP_KO_SPLIT
+  return mfma16x16x32_bf16(a[0], b[0], c);
+#endif
   c = mfma16x16x32_bf16(a[2], b[0], c);
   c = mfma16x16x32_bf16(a[0], b[2], c);
   c = mfma16x16x32_bf16(a[1], b[1], c);
@@ -244,6 +280,63 @@ __device__ __forceinline__ f32x4 mfma_bf16x6(const u32x4 (&a)[3], const u32x4 (&
   c = mfma16x16x32_bf16(a[0], b[1], c);
   c = mfma16x16x32_bf16(a[0], b[0], c);
   return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMM on the f16 matrix instructions ("f16x3", round 2): half the matrix instructions and less than half the
+// split work of bf16x6, for products that are still fp32-grade (1e-7 relative in a K = 256 GEMM, numpy emulation in
+// tests/test_f16x3_emulation.py) as long as |x| < 65504:
+//   x = xh + xm,  xh = f16(x), xm = f16(x - xh)              (11 + 11 significant bits; 5 VALU slots per PAIR: v_cvt_pk_f16_f32,
+//   w = wh + wm,  wh = f16(w), wm' = f16((w - wh) * 2^11)      two v_fma_mix_f32, v_cvt_pk_f16_f32, v_pk_mul_f16)
+//   w x ~= wm' * (xh * 2^-11) + wh * xm + wh * xh              (dropped: wm xm <= 2^-22 |w x|)
+// The weight residual is stored SCALED (host side, free) so that it is a normal f16 number for any weight magnitude; its
+// partner xs = xh * 2^-11 is exact unless |x| < 0.125, where the bits it loses are below 2^-25 of an O(1) activation.
+// MFMA operands and the conversions keep f16 subnormals (hipcc's default float_denorm_mode_16_64 = 3).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 mfma16x16x32_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// split of a pair of floats into the three B operands of f16x3: h = (xh0, xh1), s = h * 2^-11, m = (xm0, xm1)
+__device__ __forceinline__ void split_f16_pair(float x0, float x1, unsigned& h, unsigned& s, unsigned& m) {
+  const f16x2v hh = __builtin_convertvector(f32x2{x0, x1}, f16x2v);   // the FIRST read of x0 / x1 is compiler-visible
+  h = __builtin_bit_cast(unsigned, hh);
+  float r0, r1;   // x - xh in one instruction each: f16 operand read straight from the packed pair
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2v));
+  s = __builtin_bit_cast(unsigned, hh * f16x2v{(_Float16)0.00048828125f, (_Float16)0.00048828125f});
+}
+
+// D += A*B with A = (wh, wm' [, unused]), B = (xh, xs, xm), smallest terms first
+__device__ __forceinline__ f32x4 mfma_f16x3(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+  c = mfma16x16x32_f16(a[1], b[1], c);
+  c = mfma16x16x32_f16(a[0], b[2], c);
+  c = mfma16x16x32_f16(a[0], b[0], c);
+  return c;
+}
+
+// the two forms behind one name (F16 = f16x3, else bf16x6); part order of the B operand: see the two splits
+template <bool F16>
+__device__ __forceinline__ void split_pair_x(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+  if constexpr (F16) split_f16_pair(x0, x1, p0, p1, p2);
+  else split3_pair(x0, x1, p0, p1, p2);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_x(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+  if constexpr (F16) return mfma_f16x3(a, b, c);
+  else return mfma_bf16x6(a, b, c);
+}
+
+// host: the two f16 parts of a weight (RNE; wm scaled by 2^11, see above)
+inline void split2_host_f16(float x, uint16_t& h, uint16_t& m) {
+  const _Float16 hh = (_Float16)x;
+  const _Float16 mm = (_Float16)((x - (float)hh) * 2048.0f);
+  std::memcpy(&h, &hh, 2);
+  std::memcpy(&m, &mm, 2);
 }
 
 // host: round-to-nearest-even bf16 split of one float (matches v_cvt_pk_bf16_f32 for finite values)

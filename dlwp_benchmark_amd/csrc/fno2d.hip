@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void pw_mlp2_kernel(const MlpParams p) {
 // (f32x4 per 4-deep k-step, rows 4 s + g), acc2[ot][q][r] = out[co = 16 ot + 4 g + r][pixel 4 j + q].
 // ns = how many of the CIN_STEPS k-steps are populated (uniform; the fused step kernel is instantiated once for
 // CIN_STEPS = 4 and runs any in_channels <= 16 with it).
-template <int CIN_STEPS>
+template <int CIN_STEPS, bool F16 = false>
 __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const float* s_w1, const float* s_b1,
                                              const u32x4* s_w2, int npair, int lane, const f32x4 (&bias2)[2],
                                              f32x4 (&acc2)[2][4], int ns = CIN_STEPS) {
@@ -330,7 +330,7 @@ __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const
 #pragma unroll
       for (int i = 0; i < 4; ++i) {   // dword i: k-slots 2i, 2i+1 -> tile i/2, registers 2(i%2), 2(i%2)+1
         unsigned hh, mm, ll;
-        split3_pair(a1[i / 2][qq][2 * (i % 2)], a1[i / 2][qq][2 * (i % 2) + 1], hh, mm, ll);
+        split_pair_x<F16>(a1[i / 2][qq][2 * (i % 2)], a1[i / 2][qq][2 * (i % 2) + 1], hh, mm, ll);
         bg[qq][0][i] = hh;
         bg[qq][1][i] = mm;
         bg[qq][2][i] = ll;
@@ -346,14 +346,26 @@ __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const
   // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
   auto unit_mfma = [&](const u32x4(&bg)[2][3], auto qpc, auto slotc) {
     constexpr int qp = decltype(qpc)::value, slot = decltype(slotc)::value;
+    if constexpr (F16) {   // one f16 term per slot: (wm', xs) (wh, xm) (wh, xh)
+      constexpr int PA[3] = {1, 0, 0}, PB[3] = {1, 2, 0};
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+          acc2[ot][2 * qp + qq] = mfma16x16x32_f16(wa[ot][PA[slot]], bg[qq][PB[slot]], acc2[ot][2 * qp + qq]);
+    } else {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int term = 2 * slot; term < 2 * slot + 2; ++term)
+#ifdef DLWP_KO_SPLIT
+      if (term == 5)
+#endif
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq)
           acc2[ot][2 * qp + qq] = mfma16x16x32_bf16(wa[ot][PA[term]], bg[qq][PB[term]], acc2[ot][2 * qp + qq]);
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(256) void pw_proj_small_kernel(const MlpParams p) {
 // Projection MLP of one 64-pixel row segment (see pw_proj_bf16x6_kernel): bx = the 32 input channels of the
 // lane's 4 pixels as bf16x3 B operands (k order = whatever s_w1 was packed for), po[co][q] = this lane group's
 // partial sum of output co at pixel 4 j + q (to be reduced over the 4 lane groups).
-template <int CO>
+template <int CO, bool F16 = false>
 __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x4* s_w1, const float* s_b1,
                                              const float* s_w2, int ntile, int lane, float (&po)[CO][4]) {
   const int g = lane >> 4;
@@ -603,7 +615,7 @@ __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp) wa[pp] = s_w1[(t * 3 + pp) * 64 + lane];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a1[q] = mfma_bf16x6(wa, bx[q], bb);
+    for (int q = 0; q < 4; ++q) a1[q] = mfma_x<F16>(wa, bx[q], bb);
   };
   f32x4 a_cur[4], a_nxt[4], g_prev[4], g_new[4];
   fc1(0, a_cur);
@@ -639,8 +651,8 @@ __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x
     // accumulator fragments of tile t and the layer-2 FMAs of tile t-1 (fp32 lanes)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      a_nxt[2 * i] = mfma_bf16x6(wa, bx[2 * i], bb);
-      a_nxt[2 * i + 1] = mfma_bf16x6(wa, bx[2 * i + 1], bb);
+      a_nxt[2 * i] = mfma_x<F16>(wa, bx[2 * i], bb);
+      a_nxt[2 * i + 1] = mfma_x<F16>(wa, bx[2 * i + 1], bb);
       g_new[2 * i] = a_cur[2 * i];
       g_new[2 * i + 1] = a_cur[2 * i + 1];
       DLWP_GELU8_PROJ(g_new[2 * i], g_new[2 * i + 1]);
@@ -1144,6 +1156,7 @@ struct TrunkParams {
   float fwd_scale;
   int S, H, L, M1, M2, G, sample0;
   unsigned long long* trace;   // diagnostics (DLWP_TRUNK_TRACE): [workgroup][64] s_memrealtime stamps, or null
+  int trace_tid;               // the thread that stamps (DLWP_TRUNK_TRACE_WAVE * 64)
   // STEP variant (lifting and projection inside the same launch):
   ChanTable in;            // the step's input channels (folds _prepare_inputs)
   int lift_ns, lift_hid;   // populated 4-deep k-steps of the input (<= 4), lifting width (<= 256, multiple of 32)
@@ -1332,7 +1345,7 @@ __device__ __forceinline__ void fwd_dft_bf16x6(const float* s_tr, const u32x4* s
   }
 }
 
-template <int ROWS, int G, bool LL, bool STEP = false>
+template <int ROWS, int G, bool LL, bool STEP = false, bool F16 = false>
 __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkParams p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int W = 64, KP = 16, C = kC, NT = 64 * ROWS;
@@ -1414,6 +1427,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   f32x4 vv[2][4];
   if constexpr (STEP) {
     // ---- lifting: weights staged where the transpose tiles will live (they are not needed before the first DFT)
+    if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
     const int ntile_l = p.lift_hid >> 4, npair = ntile_l >> 1;
     u32x4* l_w2 = reinterpret_cast<u32x4*>(smem);                          // [npair][3][2][64]
     float* l_w1 = reinterpret_cast<float*>(l_w2 + npair * 6 * 64);         // [ntile][ns][64]
@@ -1431,13 +1445,16 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     bias2[0] = *reinterpret_cast<const f32x4*>(p.lift_b2 + 4 * g);
     bias2[1] = *reinterpret_cast<const f32x4*>(p.lift_b2 + 16 + 4 * g);
     lds_barrier();
+    if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
     f32x4 acc2[2][4];
-    lift_segment<4>(xs, l_w1, l_b1, l_w2, npair, lane, bias2, acc2, p.lift_ns);
+    lift_segment<4, F16>(xs, l_w1, l_b1, l_w2, npair, lane, bias2, acc2, p.lift_ns);
+    if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
       for (int r = 0; r < 4; ++r) vv[ot][r] = f32x4{acc2[ot][0][r], acc2[ot][1][r], acc2[ot][2][r], acc2[ot][3][r]};
     lds_barrier();   // every wave is done with the lifting weights: the region turns into transpose tiles
+    if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -1458,7 +1475,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
       *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + j * C + 16 * ct + 4 * g) = yacc[ct];
-    if (p.trace && tid == 0 && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
+    if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
   } else {
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -1502,7 +1519,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 
 #define DLWP_STAMP()                                                                                   \
   do {                                                                                                 \
-    if (p.trace && tid == 0 && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime(); \
+    if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
   DLWP_STAMP();
 
@@ -1576,13 +1593,13 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned hh, mm, ll;
-        split3_pair(vv[i >> 1][2 * (i & 1)][q], vv[i >> 1][2 * (i & 1) + 1][q], hh, mm, ll);
+        split_pair_x<F16>(vv[i >> 1][2 * (i & 1)][q], vv[i >> 1][2 * (i & 1) + 1][q], hh, mm, ll);
         bx[0][i] = hh;
         bx[1][i] = mm;
         bx[2][i] = ll;
       }
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma_bf16x6(wb[ot], bx, acc[ot][q]);
+      for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma_x<F16>(wb[ot], bx, acc[ot][q]);
     }
     if (!LL) trunk_group_wait(ctr, target, s_fail, p.spin_limit);
     DLWP_STAMP();
@@ -1842,7 +1859,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   if (*s_fail) {
     // loud failure: the host reads this word after the launch (DLWP_ERR_TIMEOUT / re-run on the unfused kernels)
     if (tid == 0 && p.fail_word) {
-      __hip_atomic_store(p.fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(p.fail_word, 1u);
       atomicAdd(p.sticky_fails, 1u);   // (per poisoned step of a workgroup: any non-zero value means failure)
     }
     const float nanv = __uint_as_float(0x7fc00000u);
@@ -1867,7 +1884,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned hh, mm, ll;
-        split3_pair(vv[i >> 1][2 * (i & 1)][q], vv[i >> 1][2 * (i & 1) + 1][q], hh, mm, ll);
+        split_pair_x<F16>(vv[i >> 1][2 * (i & 1)][q], vv[i >> 1][2 * (i & 1) + 1][q], hh, mm, ll);
         bx[q][0][i] = hh;
         bx[q][1][i] = mm;
         bx[q][2][i] = ll;
@@ -1877,7 +1894,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     auto run = [&](auto coc) {
       constexpr int CO = decltype(coc)::value;
       float po[CO][4];
-      proj_segment<CO>(bx, q_w1, q_b1, q_w2, ntile_p, lane, po);
+      proj_segment<CO, F16>(bx, q_w1, q_b1, q_w2, ntile_p, lane, po);
 #pragma unroll
       for (int co = 0; co < CO; ++co)
 #pragma unroll
@@ -1898,8 +1915,18 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
       if (*s_fail) v = f32x4{__uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u),
                              __uint_as_float(0x7fc00000u)};
       *reinterpret_cast<f32x4*>(out_p + (long long)gs * out_bs + (long long)g * HW + pix) = v;
+      if constexpr (F16) {
+        // f16x3 range guard: an activation beyond the f16 range (|x| >= 65520) turns into inf and then NaN; a non-finite
+        // OUTPUT sets bit 1 of the fail word (and the second sticky counter) and the host repeats the range on the
+        // bf16x6 kernels, whose operands have the fp32 exponent range.  (Non-finite INPUTS take the same detour.)
+        const float mag = fabsf(v[0]) + fabsf(v[1]) + fabsf(v[2]) + fabsf(v[3]);
+        if (!(mag < 3.0e38f) && p.fail_word) {
+          atomicOr(p.fail_word, 2u);
+          atomicAdd(p.sticky_fails + 1, 1u);
+        }
+      }
     }
-    if (p.trace && tid == 0 && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
+    if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
     if (st + 1 < n_steps) {
       // the next step's input rows are the ones this wave has just written: drain the stores, drop any L1 copy,
       // and let every wave finish with the projection weights before the lifting weights overwrite them
@@ -2128,6 +2155,7 @@ using namespace dlwp::fno;
 // variables only as debug defaults read at that moment.  Nothing process-global selects a kernel after that.
 struct FnoKnobs {
   bool fp32_mfma = false;     // plain fp32-MFMA kernels + unfused spectral path (cross-check form)
+  bool f16x3 = false;         // precision_form 2: the fused step kernel takes its big products as f16x3 (common.hpp)
   bool trunk = true;          // fused trunk kernel (DLWP_FNO_TRUNK=0 disables)
   int trunk_rows_forced = 0;  // DLWP_TRUNK_ROWS
   bool step = true;           // whole step in one launch (DLWP_FNO_STEP=0 disables)
@@ -2149,11 +2177,14 @@ static int env_int(const char* name, int dflt) {
 struct dlwp_fno2d_plan {
   FnoKnobs k;
   mutable std::atomic<unsigned> timeouts{0};   // statistics only: fused launches that timed out (re-run or reported)
+  mutable std::atomic<unsigned> range_reruns{0};   // statistics only: f16x3 ranges repeated on the bf16x6 kernels (non-finite output)
   DevBuf sticky;                               // device word the fused kernels add to on a timeout (reset by dlwp_fno2d_status)
   int cin = 0, hid_l = 0, hid_p = 0, cout = 0, L = 0, H = 0, W = 0;
   int cin_steps = 0;
   SpectralCore sc;
   DevBuf lift_w1p, lift_b1, lift_w2p, lift_b2, lift_w2b;
+  DevBuf lift_w2h, proj_w1hp;      // f16x3 operands of the fused step kernel (precision_form 2)
+  std::vector<DevBuf> wshp;        // likewise the skip weights, trunk k order
   DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v, proj_w1b, proj_w1bp;   // w1bp: k order of the trunk's resident activation
   int proj_co = 0;  // outputs handled by pw_proj_small_kernel (1, 2 or 4), 0 = generic MFMA path
   std::vector<DevBuf> wt, wsp, sbias, wsb, wsbp;   // wsbp: bf16x3 skip weights in the trunk kernel's k order
@@ -2169,13 +2200,18 @@ static void pack_w1(std::vector<float>& dst, const float* w1, int hid, int cin, 
       }
 }
 // bf16x6 A operands of a [rows][K = 32] matrix block: [rows/16][3 parts][64 lanes][4 dwords]
-static void pack_a_bf16x3(std::vector<uint32_t>& dst, const float* w, int rows, int ld) {
+// f16: the same layout holding the f16x3 parts (wh, wm' = (w - wh) * 2^11, 0) -- common.hpp
+static void pack_a_bf16x3(std::vector<uint32_t>& dst, const float* w, int rows, int ld, bool f16 = false) {
   dst.assign((size_t)(rows / 16) * 3 * 64 * 4, 0u);
   for (int t = 0; t < rows / 16; ++t)
     for (int l = 0; l < 64; ++l)
       for (int d = 0; d < 4; ++d) {
-        uint16_t h[2], m[2], lo[2];
-        for (int e = 0; e < 2; ++e) split3_host(w[(size_t)(16 * t + (l & 15)) * ld + 8 * (l >> 4) + 2 * d + e], h[e], m[e], lo[e]);
+        uint16_t h[2], m[2], lo[2] = {0, 0};
+        for (int e = 0; e < 2; ++e) {
+          const float v = w[(size_t)(16 * t + (l & 15)) * ld + 8 * (l >> 4) + 2 * d + e];
+          if (f16) split2_host_f16(v, h[e], m[e]);
+          else split3_host(v, h[e], m[e], lo[e]);
+        }
         const size_t base = ((size_t)t * 3 * 64 + l) * 4 + d;
         dst[base + 0 * 64 * 4] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
         dst[base + 1 * 64 * 4] = (uint32_t)m[0] | ((uint32_t)m[1] << 16);
@@ -2185,18 +2221,20 @@ static void pack_a_bf16x3(std::vector<uint32_t>& dst, const float* w, int rows, 
 
 // bf16x6 A operands of layer 2 of the lifting MLP: W2 [32][hid] -> [hid/32][3 parts][2 out tiles][64 lanes][4 dwords];
 // k-slot (g, jj) of tile pair u is hidden channel 16*(2u + jj/4) + 4g + jj%4 (accumulator order of layer 1)
-static void pack_lift_w2_bf16x3(std::vector<uint32_t>& dst, const float* w2, int hid) {
+static void pack_lift_w2_bf16x3(std::vector<uint32_t>& dst, const float* w2, int hid, bool f16 = false) {
   const int npair = hid / 32;
   dst.assign((size_t)npair * 3 * 2 * 64 * 4, 0u);
   for (int u = 0; u < npair; ++u)
     for (int ot = 0; ot < 2; ++ot)
       for (int l = 0; l < 64; ++l)
         for (int d = 0; d < 4; ++d) {
-          uint16_t h[2], m[2], lo[2];
+          uint16_t h[2], m[2], lo[2] = {0, 0};
           for (int e = 0; e < 2; ++e) {
             const int jj = 2 * d + e, g = l >> 4;
             const int ch = 16 * (2 * u + jj / 4) + 4 * g + jj % 4;
-            split3_host(w2[(size_t)(16 * ot + (l & 15)) * hid + ch], h[e], m[e], lo[e]);
+            const float v = w2[(size_t)(16 * ot + (l & 15)) * hid + ch];
+            if (f16) split2_host_f16(v, h[e], m[e]);
+            else split3_host(v, h[e], m[e], lo[e]);
           }
           auto at = [&](int part) -> uint32_t& { return dst[((((size_t)u * 3 + part) * 2 + ot) * 64 + l) * 4 + d]; };
           at(0) = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
@@ -2237,7 +2275,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
   DLWP_REQUIRE(d->lift_w1 && d->lift_b1 && d->lift_w2 && d->lift_b2 && d->spec_w && d->spec_b && d->skip_w &&
                    d->proj_w1 && d->proj_b1 && d->proj_w2 && d->proj_b2 && d->rows_in && d->rows_out,
                DLWP_ERR_INVALID_ARGUMENT, "null weight pointer");
-  DLWP_REQUIRE(d->precision_form == 0 || d->precision_form == 1, DLWP_ERR_INVALID_ARGUMENT, "precision_form %d not in {0, 1}",
+  DLWP_REQUIRE(d->precision_form >= 0 && d->precision_form <= 2, DLWP_ERR_INVALID_ARGUMENT, "precision_form %d not in {0, 1, 2}",
                d->precision_form);
   DLWP_REQUIRE(d->on_timeout == 0 || d->on_timeout == 1, DLWP_ERR_INVALID_ARGUMENT, "on_timeout %d not in {0, 1}", d->on_timeout);
   DLWP_REQUIRE(d->debug_spin_limit >= 0, DLWP_ERR_INVALID_ARGUMENT, "debug_spin_limit must be >= 0");
@@ -2246,6 +2284,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
     FnoKnobs& k = p->k;
     // descriptor first; the environment only supplies debug defaults, read HERE and never again
     k.fp32_mfma = d->precision_form == 1 || env_int("DLWP_FP32_MFMA", 0) != 0;
+    k.f16x3 = !k.fp32_mfma && (d->precision_form == 2 || env_int("DLWP_FNO_F16X3", 0) != 0);
     k.trunk = env_int("DLWP_FNO_TRUNK", 1) != 0 && d->launch_form != 3;
     k.trunk_rows_forced = env_int("DLWP_TRUNK_ROWS", 0);
     k.step = env_int("DLWP_FNO_STEP", 1) != 0 && d->launch_form != 2 && d->launch_form != 3;
@@ -2286,6 +2325,11 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
       pack_lift_w2_bf16x3(wb, d->lift_w2, p->hid_l);
       if ((e = p->lift_w2b.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
       if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+      if (p->k.f16x3) {
+        pack_lift_w2_bf16x3(wb, d->lift_w2, p->hid_l, true);
+        if ((e = p->lift_w2h.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+      }
     }
     pack_w1(tmp, d->proj_w1, p->hid_p, kC, 8);
     if ((e = up(p->proj_w1p, tmp)) != hipSuccess) break;
@@ -2318,13 +2362,18 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
         pack_a_bf16x3(wb, wperm.data(), p->hid_p, kC);
         if ((e = p->proj_w1bp.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+        if (p->k.f16x3) {
+          pack_a_bf16x3(wb, wperm.data(), p->hid_p, kC, true);
+          if ((e = p->proj_w1hp.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
+          if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+        }
       }
     }
     std::vector<float> b2(16, 0.f);
     for (int i = 0; i < p->cout; ++i) b2[i] = d->proj_b2[i];
     if ((e = up(p->proj_b2, b2)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
-    p->wt.resize(p->L); p->wsp.resize(p->L); p->sbias.resize(p->L); p->wsb.resize(p->L); p->wsbp.resize(p->L);
+    p->wt.resize(p->L); p->wsp.resize(p->L); p->sbias.resize(p->L); p->wsb.resize(p->L); p->wsbp.resize(p->L); p->wshp.resize(p->L);
     for (int l = 0; l < p->L && e == hipSuccess; ++l) {
       std::vector<float> w((size_t)d->n_cols * d->n_rows * kC * kC * 2, 0.f);
       pack_spectral(w, d->spec_w[l], kC, kC, d->n_rows, d->n_cols, d->n_rows, 0);
@@ -2350,6 +2399,11 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
         std::vector<uint32_t> wsbp;
         pack_a_bf16x3(wsbp, wperm.data(), kC, kC);
         if ((e = p->wsbp[l].upload(wsbp.data(), wsbp.size() * 4, s)) != hipSuccess) break;
+        if (p->k.f16x3) {
+          if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+          pack_a_bf16x3(wsbp, wperm.data(), kC, kC, true);
+          if ((e = p->wshp[l].upload(wsbp.data(), wsbp.size() * 4, s)) != hipSuccess) break;
+        }
       }
       if ((e = p->sbias[l].upload(d->spec_b + (size_t)l * kC, (size_t)kC * 4, s)) != hipSuccess) break;
       if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
@@ -2360,8 +2414,8 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
     return fail(DLWP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
   }
   {
-    const unsigned zero = 0;
-    hipError_t se = p->sticky.upload(&zero, 4, s);
+    const unsigned zero[2] = {0, 0};   // [0] hand-off timeouts, [1] f16x3 ranges with a non-finite output
+    hipError_t se = p->sticky.upload(zero, 8, s);
     if (se == hipSuccess) se = hipStreamSynchronize(s);
     if (se != hipSuccess) { delete p; return fail(DLWP_ERR_HIP, "plan allocation failed: %s", hipGetErrorString(se)); }
   }
@@ -2378,6 +2432,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
 }
 
 extern "C" uint32_t dlwp_fno2d_timeouts(const dlwp_fno2d_plan* plan) { return plan ? plan->timeouts.load() : 0u; }
+extern "C" uint32_t dlwp_fno2d_range_reruns(const dlwp_fno2d_plan* plan) { return plan ? plan->range_reruns.load() : 0u; }
 
 extern "C" int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan) {
   delete plan;
@@ -2534,8 +2589,14 @@ int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, Tru
   return DLWP_OK;
 }
 template <int G>
-hipError_t step_launch_one(const TrunkParams& tp, hipStream_t s) {
+hipError_t step_launch_one(const TrunkParams& tp, hipStream_t s, bool f16) {
   constexpr size_t lds = trunk_lds(8);
+  if (f16) {
+    hipError_t e = allow_lds(fno_trunk_kernel<8, G, true, true, true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fno_trunk_kernel<8, G, true, true, true>), dim3(tp.S * G), dim3(512), lds, s, tp);
+    return hipGetLastError();
+  }
   hipError_t e = allow_lds(fno_trunk_kernel<8, G, true, true>, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((fno_trunk_kernel<8, G, true, true>), dim3(tp.S * G), dim3(512), lds, s, tp);
@@ -2605,6 +2666,8 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
     static unsigned long long* trace_buf = nullptr;
     static int traced = 0;
     tp.trace = nullptr;
+    static const char* trace_wave = getenv("DLWP_TRUNK_TRACE_WAVE");
+    tp.trace_tid = trace_wave ? 64 * atoi(trace_wave) : 0;
     if (trace_path && traced < 4) {
       if (!trace_buf) DLWP_HIP_CHECK(hipMalloc(&trace_buf, (size_t)1024 * 64 * 8));
       DLWP_HIP_CHECK(hipMemsetAsync(trace_buf, 0, (size_t)1024 * 64 * 8, s));
@@ -2627,9 +2690,15 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
         tp.r_nconst = io->n_const; tp.r_npresc = io->n_presc; tp.r_nprog = io->n_prog; tp.r_T = io->T; tp.r_ctx = io->ctx;
         tp.r_t0 = io->t0;
       }
-      if (G == 4) le = step_launch_one<4>(tp, s);
-      else if (G == 8) le = step_launch_one<8>(tp, s);
-      else if (G == 16) le = step_launch_one<16>(tp, s);
+      const bool f16 = p->k.f16x3 && p->lift_w2h.p && p->proj_w1hp.p && !io->lift_only;
+      if (f16) {   // f16x3 operands (the unfused kernels and the plain trunk keep bf16x6)
+        tp.lift_w2b = p->lift_w2h.as<u32x4>();
+        tp.proj_w1b = p->proj_w1hp.as<u32x4>();
+        for (int l = 0; l < kTrunkMaxLayers; ++l) tp.wsb[l] = p->wshp[l < p->L ? l : 0].as<u32x4>();
+      }
+      if (G == 4) le = step_launch_one<4>(tp, s, f16);
+      else if (G == 8) le = step_launch_one<8>(tp, s, f16);
+      else if (G == 16) le = step_launch_one<16>(tp, s, f16);
     } else
     if (rows == 8 && G == 4) le = trunk_launch_one<8, 4>(tp, s, p->k.ll);
     else if (rows == 8 && G == 8) le = trunk_launch_one<8, 8>(tp, s, p->k.ll);
@@ -2712,7 +2781,8 @@ int32_t fno_project(const dlwp_fno2d_plan* p, const float* hin, int B, float* ou
 }
 
 // Reads the fail word of the fused launches enqueued so far on `s` (synchronises the stream).  Returns 1 if a hand-off
-// timed out, 0 if not, < 0 on a HIP error.  Skipped (returns 0) while the stream is being captured into a graph.
+// timed out (bit 0) and / or an f16x3 range produced a non-finite output (bit 1), 0 if neither, < 0 on a HIP error.
+// Skipped (returns 0) while the stream is being captured into a graph.
 int read_fail_word(const FnoWorkspace& ws, hipStream_t s) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
@@ -2725,7 +2795,7 @@ int read_fail_word(const FnoWorkspace& ws, hipStream_t s) {
   *h_word = 0u;
   if (hipMemcpyAsync(h_word, ws.fail, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
-  return *h_word ? 1 : 0;
+  return (int)(*h_word & 3u);
 }
 
 // one backbone step: x (channel table) -> out (+ resid)
@@ -2844,9 +2914,13 @@ extern "C" int32_t dlwp_fno2d_forward_f32(const dlwp_fno2d_plan* plan, const flo
     const int f = read_fail_word(ws, s);
     if (f < 0) return fail(DLWP_ERR_HIP, "reading the fused kernel's fail word failed");
     if (f == 0) return DLWP_OK;
-    plan->timeouts.fetch_add(1);
-    if (plan->k.on_timeout == 1)
-      return fail(DLWP_ERR_TIMEOUT, "fused FNO step: a workgroup hand-off exceeded its spin bound (output poisoned with NaN)");
+    if (f & 1) {
+      plan->timeouts.fetch_add(1);
+      if (plan->k.on_timeout == 1)
+        return fail(DLWP_ERR_TIMEOUT, "fused FNO step: a workgroup hand-off exceeded its spin bound (output poisoned with NaN)");
+    } else {
+      plan->range_reruns.fetch_add(1);   // f16x3: non-finite output -> the same step on the bf16x6 kernels
+    }
   }
   return fail(DLWP_ERR_TIMEOUT, "unreachable: the unfused kernels have no hand-offs");
 }
@@ -2856,15 +2930,19 @@ extern "C" int32_t dlwp_fno2d_status(const dlwp_fno2d_plan* plan, void* stream) 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   thread_local unsigned* h_word = nullptr;   // pinned, one per host thread; never freed
   if (!h_word) DLWP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_word), 64, hipHostMallocDefault));
-  *h_word = 0u;
-  DLWP_HIP_CHECK(hipMemcpyAsync(h_word, plan->sticky.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  DLWP_HIP_CHECK(hipMemsetAsync(plan->sticky.p, 0, sizeof(unsigned), s));
+  h_word[0] = h_word[1] = 0u;
+  DLWP_HIP_CHECK(hipMemcpyAsync(h_word, plan->sticky.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  DLWP_HIP_CHECK(hipMemsetAsync(plan->sticky.p, 0, 2 * sizeof(unsigned), s));
   DLWP_HIP_CHECK(hipStreamSynchronize(s));
-  if (*h_word) {
+  if (h_word[0]) {
     plan->timeouts.fetch_add(1);
     return fail(DLWP_ERR_TIMEOUT, "fused FNO kernels: %u workgroup(s) exceeded a hand-off spin bound since the last status call "
-                "(outputs of those launches are poisoned with NaN)", *h_word);
+                "(outputs of those launches are poisoned with NaN)", h_word[0]);
   }
+  if (h_word[1])
+    return fail(DLWP_ERR_RANGE, "fused FNO kernels (f16x3): %u non-finite output vector(s) since the last status call -- an "
+                "activation beyond the f16 range or a non-finite input; repeat with precision_form 0 (bf16x6) or with the "
+                "per-call check, which repeats such a range on the bf16x6 kernels by itself", h_word[1]);
   return DLWP_OK;
 }
 
@@ -2891,10 +2969,14 @@ static int32_t fno_rollout_impl(const dlwp_fno2d_plan* plan, const float* consta
   const int f = read_fail_word(ws, reinterpret_cast<hipStream_t>(stream));
   if (f < 0) return fail(DLWP_ERR_HIP, "reading the fused kernel's fail word failed");
   if (f == 0) return DLWP_OK;
-  plan->timeouts.fetch_add(1);
-  if (plan->k.on_timeout == 1)
-    return fail(DLWP_ERR_TIMEOUT, "fused FNO rollout: a workgroup hand-off exceeded its spin bound (steps [%d, %d) poisoned "
-                "with NaN); were all %d workgroups of the launch resident?", step_begin, step_end, batch * (plan->H / 8));
+  if (f & 1) {
+    plan->timeouts.fetch_add(1);
+    if (plan->k.on_timeout == 1)
+      return fail(DLWP_ERR_TIMEOUT, "fused FNO rollout: a workgroup hand-off exceeded its spin bound (steps [%d, %d) poisoned "
+                  "with NaN); were all %d workgroups of the launch resident?", step_begin, step_end, batch * (plan->H / 8));
+  } else {
+    plan->range_reruns.fetch_add(1);   // f16x3: non-finite output -> the same range on the bf16x6 kernels
+  }
   return fno_rollout_once(plan, constants, n_const, prescribed, n_presc, prognostic, n_prog, batch, n_time, context, out,
                           workspace, workspace_bytes, stream, nullptr, step_begin, step_end, true, &fused);
 }

@@ -51,6 +51,7 @@ SIGNATURES = {
     "dlwp_fno2d_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
     "dlwp_fno2d_status": (c_int32, [c_void_p, c_void_p]),
     "dlwp_fno2d_timeouts": (ctypes.c_uint32, [c_void_p]),
+    "dlwp_fno2d_range_reruns": (ctypes.c_uint32, [c_void_p]),
     "dlwp_fno2d_forward_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "dlwp_fno2d_rollout_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                                          c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),

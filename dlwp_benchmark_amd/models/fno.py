@@ -169,7 +169,11 @@ class FNO2DModule(HipBackbone):
         self._plan = None
         self._plan_key = None
         # execution form of the plan (struct dlwp_fno2d_desc): per-module state, fixed per plan, no process-wide switch
-        self.precision_form = "bf16x6"   # or "fp32_mfma": plain fp32-MFMA kernels + unfused spectral path (cross-check)
+        # "f16x3" (default): the fused step kernel forms its big fp32 products from two-part f16 splits (fp32-GEMM accuracy
+        # for |activation| < 65504; a range with a non-finite output is repeated on the bf16x6 kernels by itself);
+        # "bf16x6": three-part bf16 splits everywhere (fp32 exponent range); "fp32_mfma": plain fp32-MFMA kernels +
+        # unfused spectral path (independent cross-check)
+        self.precision_form = "f16x3"
         self.launch_form = 0             # 0 fewest launches, 1 one per step, 2 three per step, 3 unfused kernels
         self.on_timeout = "rerun"        # or "raise": DLWP_ERR_TIMEOUT instead of the automatic re-run on the unfused kernels
         self.check = "per_call"          # or "deferred": asynchronous calls, the caller verifies with .check() (see there)
@@ -178,7 +182,7 @@ class FNO2DModule(HipBackbone):
     def set_execution_form(self, precision_form: Optional[str] = None, launch_form: Optional[int] = None,
                            on_timeout: Optional[str] = None, check: Optional[str] = None):
         if precision_form is not None:
-            if precision_form not in ("bf16x6", "fp32_mfma"):
+            if precision_form not in ("f16x3", "bf16x6", "fp32_mfma"):
                 raise _lib.DlwpError(f"unknown precision_form {precision_form!r}")
             self.precision_form = precision_form
         if launch_form is not None:
@@ -208,6 +212,10 @@ class FNO2DModule(HipBackbone):
     def fused_timeouts(self) -> int:
         """fused launches of the current plan whose hand-off spin ran out (re-run on the unfused kernels or raised)"""
         return int(_lib.load().dlwp_fno2d_timeouts(self._plan)) if self._plan is not None else 0
+
+    def range_reruns(self) -> int:
+        """f16x3 step ranges of the current plan that were repeated on the bf16x6 kernels (non-finite output)"""
+        return int(_lib.load().dlwp_fno2d_range_reruns(self._plan)) if self._plan is not None else 0
 
     # ------------------------------------------------------------------ plan management
     def _destroy_plan(self):
@@ -276,7 +284,7 @@ class FNO2DModule(HipBackbone):
         d.proj_b1 = ptr(host(f.projection.fcs[0].bias))
         d.proj_w2 = ptr(host(f.projection.fcs[1].weight).reshape(d.out_channels, -1).contiguous())
         d.proj_b2 = ptr(host(f.projection.fcs[1].bias))
-        d.precision_form = 1 if self.precision_form == "fp32_mfma" else 0
+        d.precision_form = {"bf16x6": 0, "fp32_mfma": 1, "f16x3": 2}[self.precision_form]
         d.launch_form = int(self.launch_form)
         d.on_timeout = 1 if self.on_timeout == "raise" else 0
         d.unchecked = 1 if self.check == "deferred" else 0

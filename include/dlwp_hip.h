@@ -33,7 +33,8 @@ typedef enum dlwp_status {
   DLWP_ERR_UNSUPPORTED = -2,
   DLWP_ERR_HIP = -3,
   DLWP_ERR_WORKSPACE = -4,
-  DLWP_ERR_TIMEOUT = -5      /* a fused kernel's inter-workgroup hand-off exceeded its spin bound (output poisoned) */
+  DLWP_ERR_TIMEOUT = -5,     /* a fused kernel's inter-workgroup hand-off exceeded its spin bound (output poisoned) */
+  DLWP_ERR_RANGE = -6        /* dlwp_fno2d_status only: an unchecked f16x3 launch produced a non-finite output */
 } dlwp_status;
 
 /* library version, major*10000 + minor*100 + patch */
@@ -79,7 +80,13 @@ typedef struct dlwp_fno2d_desc {
   int32_t precision_form;      /* 0 (default): the fp32 channel GEMMs run as "bf16x6" -- each fp32 operand split exactly
                                   into three bf16 parts, the six significant cross products accumulated in fp32 on the
                                   bf16 matrix pipe (fp32-GEMM accuracy) -- and the fused kernels;
-                                  1: plain fp32-MFMA kernels and the unfused spectral path (independent cross-check) */
+                                  1: plain fp32-MFMA kernels and the unfused spectral path (independent cross-check);
+                                  2: "f16x3" in the fused step kernel -- operands split into two f16 parts (22 significant
+                                  bits, the weight residual stored scaled), three products on the f16 matrix instructions:
+                                  fp32-GEMM accuracy for |activation| < 65504 at half the matrix instructions and split
+                                  work.  A range whose output is not finite is repeated on the
+                                  bf16x6 kernels (checked calls) or reported by dlwp_fno2d_status as DLWP_ERR_RANGE
+                                  (unchecked = 1).  Kernels other than the fused step keep bf16x6. */
   int32_t launch_form;         /* 0 (default): fewest launches the shapes allow (whole rollout range in one persistent
                                   launch); 1: one launch per step; 2: three launches per step; 3: unfused kernels */
   int32_t on_timeout;          /* a fused launch whose hand-off spin ran out: 0 (default) re-run the range on the unfused
@@ -95,10 +102,13 @@ int32_t dlwp_fno2d_plan_destroy(dlwp_fno2d_plan* plan);
 size_t dlwp_fno2d_workspace_bytes(const dlwp_fno2d_plan* plan, int32_t batch);
 /* Deferred check for plans created with unchecked = 1 (fully asynchronous calls): synchronises `stream` and returns
  * DLWP_ERR_TIMEOUT if any fused launch of this plan timed out since the previous status call (a plan-owned device counter
- * the kernels add to; reset here).  The outputs of such launches are poisoned with NaN. */
+ * the kernels add to; reset here).  The outputs of such launches are poisoned with NaN.  DLWP_ERR_RANGE: an f16x3 launch
+ * (precision_form 2) wrote a non-finite output since the previous status call. */
 int32_t dlwp_fno2d_status(const dlwp_fno2d_plan* plan, void* stream);
 /* statistics: fused launches of this plan that timed out so far (re-run or reported) */
 uint32_t dlwp_fno2d_timeouts(const dlwp_fno2d_plan* plan);
+/* statistics: f16x3 step ranges of this plan (precision_form 2) repeated on the bf16x6 kernels after a non-finite output */
+uint32_t dlwp_fno2d_range_reruns(const dlwp_fno2d_plan* plan);
 
 /* One backbone step WITHOUT the residual: y = fno(x).  Replaces `self.fno(x_t)` at fno.py:103.
  * x_dev [B, in, H, W], y_dev [B, out, H, W], both contiguous fp32. */

@@ -3,6 +3,8 @@ oracle (CPU restatement, oracle/restate/fno.py) and vs the reference-generated g
 
 Tolerance (BASELINE.json north_star): per-step relative L2 <= 1e-5 in fp32.
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -271,6 +273,55 @@ def test_fused_timeout_is_loud_and_falls_back():
     hip.set_execution_form(check="per_call")
     again = hip(prognostic=p)
     assert hip.fused_timeouts() == 0 and torch.equal(again, good)
+
+
+def test_f16x3_form_matches_bf16x6_and_oracle():
+    """precision_form "f16x3" (default of the module; dlwp_fno2d_desc.precision_form = 2): the fused step kernel forms its
+    big fp32 products from two-part f16 splits.  Same bound against the oracle as the bf16x6 form (per-step rel-L2 <= 1e-5
+    over a 20-step rollout), and the two forms agree far below that bound."""
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    ref, hip = _make_pair(**NS_KW)
+    assert hip.precision_form == "f16x3"
+    _, _, prog = navier_stokes(32, 21)
+    p = prog.to(_dev())
+    with torch.no_grad():
+        want = ref(prognostic=prog[:4])
+    a = hip(prognostic=p)
+    assert hip.range_reruns() == 0
+    hip.set_execution_form(precision_form="bf16x6")
+    b = hip(prognostic=p)
+    ea, eb = per_step_rel_l2(a[:4], want), per_step_rel_l2(b[:4], want)
+    assert max(ea) <= TOL and max(eb) <= TOL, (ea, eb)
+    assert max(ea) <= 2.0 * max(eb) + 2e-7, (max(ea), max(eb))     # fp32-grade: not measurably worse than bf16x6
+    assert max(per_step_rel_l2(a, b)) <= 2e-6
+
+
+def test_f16x3_range_guard_repeats_on_bf16x6():
+    """Activations beyond the f16 range (|x| >= 65520) become inf in the f16x3 operands.  The fused kernel flags a non-finite
+    OUTPUT (bit 1 of its fail word / the second sticky counter); a checked call repeats the range on the bf16x6 kernels
+    (fp32 exponent range) and returns their result, a deferred-check evaluation raises DLWP_ERR_RANGE (status -6)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    ref, hip = _make_pair(**NS_KW)
+    _, _, prog = navier_stokes(8, 3)
+    big = (prog * 3.0e6).to(_dev())          # lifting activations ~1e6: finite in fp32 / bf16 parts, inf in f16
+    exact = copy.deepcopy(hip).set_execution_form(precision_form="bf16x6", launch_form=3)
+    want = exact(prognostic=big)
+    assert torch.isfinite(want).all()
+    got = hip(prognostic=big)
+    assert hip.range_reruns() == 1, "the range guard did not fire"
+    assert torch.isfinite(got).all()
+    assert max(per_step_rel_l2(got, want)) <= 1e-6
+    small = hip(prognostic=prog.to(_dev()))
+    assert hip.range_reruns() == 1 and torch.isfinite(small).all()
+    hip.set_execution_form(check="deferred")
+    hip(prognostic=big)
+    with pytest.raises(L.DlwpError, match="status -6"):
+        hip.verify()
+    hip(prognostic=prog.to(_dev()))
+    hip.verify()
 
 
 def test_tfno_matches_fno_with_reconstructed_weights():

@@ -21,7 +21,7 @@ if not os.path.exists(path) or os.environ.get("DLWP_TRUNK_TRACE"):
 rows = [list(map(int, l.split())) for l in open(path)]
 names = ["start"]
 if os.environ.get("DLWP_FNO_STEP", "1") != "0":
-    names = ["lift done", "trunk setup"]
+    names = ["step top", "lift staged", "lift seg", "lift all waves", "lift done", "trunk setup"]
 for l in range(4):
     names += [f"L{l} y-ready", f"L{l} P1 done", f"L{l} barrier1", f"L{l} P2 done", f"L{l} barrier2", f"L{l} P3+sync",
               f"L{l} skip+idft"]
@@ -36,4 +36,4 @@ for launch in sorted({r[0] for r in rows})[-int(os.environ.get('TRACE_LAUNCHES',
     prev = rel[:, 0]
     for k in range(1, t.shape[1]):
         d = rel[:, k] - rel[:, k - 1]
-        print(f"  {names[k] if k < len(names) else k:>14}: at mean {rel[:, k].mean():6.2f} us | phase mean {d.mean():5.2f} min {d.min():5.2f} max {d.max():5.2f}")
+        print(f"  {names[k % len(names)]:>14}: at mean {rel[:, k].mean():6.2f} us | phase mean {d.mean():5.2f} min {d.min():5.2f} max {d.max():5.2f}")
