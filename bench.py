@@ -166,7 +166,7 @@ def _attn_tag(name, a):
     if name.startswith("dlwp_window_attn"):
         d = a[0]._obj
         return (tuple(d.padded), tuple(d.window), int(d.heads), int(d.head_dim), int(a[5]), int(d.use_mask))   # a[5] = batch
-    if name.startswith("dlwp_linear_") and not name.endswith("pack_f32"):
+    if name.startswith("dlwp_linear_") and "pack" not in name:
         return (int(a[5]), int(a[6]), int(a[7]), int(a[8]), a[3] is not None)      # rows, in, out, act, residual operand
     return None
 
@@ -198,7 +198,8 @@ def bench_other_configs(device, only=None, reps=2):
             continue
         # "bf16": bf16 window attention only; "bf16all": bf16 attention AND bf16 Linear operands (the autocast(bfloat16)
         # analogue BASELINE configs[2] names); fp32 accumulation, LayerNorm and residual stream in all of them
-        variants = ["fp32"] + (["bf16", "bf16all"] if cls in ("SwinTransformer", "PanguWeather") else [])
+        # "f16x3": fp32 attention, the Linears in the fp32-grade f16x3 form (two-part f16 splits, three products)
+        variants = ["fp32"] + (["f16x3", "bf16", "bf16all"] if cls in ("SwinTransformer", "PanguWeather") else [])
         model = getattr(M, cls)(**cfg)
         sha = fill_state_dict(model, gain=gain)
         model = model.to(device).eval()
@@ -221,11 +222,12 @@ def bench_other_configs(device, only=None, reps=2):
             if str(gz["sha"]) == sha:
                 want = torch.from_numpy(gz["y"])
         for variant in variants:
-            prec = "fp32" if variant == "fp32" else "bf16"
+            prec = "fp32" if variant in ("fp32", "f16x3") else "bf16"
             if hasattr(model, "set_attention_precision"):
                 model.set_attention_precision(prec)
-                model.set_linear_form("bf16" if variant == "bf16all" else "bf16x6")
+                model.set_linear_form({"bf16all": "bf16", "f16x3": "f16x3"}.get(variant, "bf16x6"))
             what = {"fp32": "fp32", "bf16": "bf16 window attention (fp32 elsewhere)",
+                    "f16x3": "fp32 (Linear products from exact two-part f16 splits, dlwp_linear_f16x3; fp32-accurate attention)",
                     "bf16all": "bf16 window attention and bf16 Linear operands (fp32 accumulation, LayerNorm, residual stream)"}[variant]
             entry = {"workload": f"{cls} {h}x{w}, {cfg['prognostic_channels']} prognostic ch, {steps}-step rollout, {what}",
                      "batch": batch, "rollout_steps": steps, "weights": "deterministic filler sha256:" + sha[:16],
@@ -272,7 +274,7 @@ def bench_other_configs(device, only=None, reps=2):
             lin = _linear_roofline(summ)
             if lin is not None:
                 entry["roofline_linear"] = lin
-            res[tag + {"fp32": "", "bf16": "_bf16attn", "bf16all": "_bf16"}[variant]] = entry
+            res[tag + {"fp32": "", "f16x3": "_f16x3", "bf16": "_bf16attn", "bf16all": "_bf16"}[variant]] = entry
         del model, out
         torch.cuda.empty_cache()
     return res
@@ -282,7 +284,7 @@ def _linear_roofline(summ):
     """the Linear kernel's costliest shape class: algorithmic flops 2 M K N (bias / GELU / residual not counted) / event time,
     priced against the fp32 matrix peak for dlwp_linear_f32 (fp32-accurate: six bf16 products per fp32 one are not credited)
     and against the dense bf16 peak for dlwp_linear_bf16."""
-    lin = {k: v for k, v in summ.items() if k[0] in ("dlwp_linear_f32", "dlwp_linear_bf16")}
+    lin = {k: v for k, v in summ.items() if k[0] in ("dlwp_linear_f32", "dlwp_linear_bf16", "dlwp_linear_f16x3")}
     if not lin:
         return None
     (name, tag), v = max(lin.items(), key=lambda kv: kv[1]["total_ms"])
@@ -297,7 +299,7 @@ def _linear_roofline(summ):
             "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
             "hbm_view_GBps": by / (v["avg_ms"] * 1e-3) / 1e9, "avg_launch_ms": v["avg_ms"], "launches_per_rollout": v["calls"],
             "all_linear_ms_per_rollout": tot,
-            "note": "dlwp_linear_f32 runs its products on the bf16 pipe: against the fp32 matrix peak its fraction can exceed 1"}
+            "note": "dlwp_linear_f32 / _f16x3 run their products on the bf16 / f16 matrix pipe: against the fp32 matrix peak their fraction can exceed 1"}
 
 
 def _other_roofline(cls, cfg, batch, h, w, summ, prec):

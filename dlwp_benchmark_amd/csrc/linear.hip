@@ -63,12 +63,15 @@ struct Cursor {          // one (tile, k-step) position of this workgroup's flat
   int slab, nt, ks, left;    // slab index inside the XCD, n-tile, k-step, tiles after this one
 };
 
-template <int BN, int NP>
+// F16 (dlwp_linear_f16x3, NP = 3): the "f16x3" form of common.hpp -- x parts (xh, xh * 2^-11, xm), W parts (wh, wm' = (w - wh) * 2^11),
+// three f16 products per output instead of six bf16 ones, 5 instead of 11 split slots per pair; only TWO W images are staged.
+template <int BN, int NP, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   constexpr int TN = BN / 32;                        // 16-row W tiles per wave (wave tile: 64 m x BN/2 n)
+  constexpr int NPW = F16 ? 2 : NP;                  // W parts staged per k-step
   constexpr int XBYTES = NP * 8192;                  // x tile: NP parts x 128 rows x 64 bytes
-  constexpr int WPART = BN * 64, WSTAGE = NP * WPART;
-  constexpr int CH = NP * BN * 4;                    // 16-byte chunks per W stage
+  constexpr int WPART = BN * 64, WSTAGE = NPW * WPART;
+  constexpr int CH = NPW * BN * 4;                   // 16-byte chunks per W stage
   constexpr int PIECES = CH / 64;                    // 1 KiB LDS-DMA pieces (16 rows x 64 bytes) per W stage
   constexpr int G = (PIECES + 3) / 4;                // pieces per wave and k-step
   extern __shared__ __align__(1024) unsigned char smem[];
@@ -159,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
       unsigned char* d = smem + r * 64 + (((c4 >> 1) ^ swz(r)) << 4) + ((c4 & 1) << 3);
       if constexpr (NP == 3) {
         unsigned h0, m0_, l0, h1, m1, l1;
-        split3_pair(src[q][0], src[q][1], h0, m0_, l0);
-        split3_pair(src[q][2], src[q][3], h1, m1, l1);
+        split_pair_x<F16>(src[q][0], src[q][1], h0, m0_, l0);
+        split_pair_x<F16>(src[q][2], src[q][3], h1, m1, l1);
         *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
         *reinterpret_cast<uint2*>(d + 8192) = uint2{m0_, m1};
         *reinterpret_cast<uint2*>(d + 16384) = uint2{l0, l1};
@@ -265,9 +268,9 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
 #pragma unroll
       for (int part = 0; part < NP; ++part) xb[a][part] = *reinterpret_cast<const u32x4*>(xfrag + part * 8192 + a * 1024);
     const unsigned char* wf = wfrag + cur * WSTAGE;
-    u32x4 wa[NP];          // the first W fragments too: the MFMAs can start right behind the barrier
+    u32x4 wa[NPW];         // the first W fragments too: the MFMAs can start right behind the barrier
 #pragma unroll
-    for (int part = 0; part < NP; ++part) wa[part] = *reinterpret_cast<const u32x4*>(wf + part * WPART);
+    for (int part = 0; part < NPW; ++part) wa[part] = *reinterpret_cast<const u32x4*>(wf + part * WPART);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // every wave holds its x fragments: the x tile is free
     asm volatile("" ::: "memory");
@@ -281,9 +284,16 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
     for (int b = 0; b < TN; ++b) {
       if (b > 0) {
 #pragma unroll
-        for (int part = 0; part < NP; ++part) wa[part] = *reinterpret_cast<const u32x4*>(wf + part * WPART + b * 1024);
+        for (int part = 0; part < NPW; ++part) wa[part] = *reinterpret_cast<const u32x4*>(wf + part * WPART + b * 1024);
       }
-      if constexpr (NP == 3) {
+      if constexpr (F16) {
+        // three products, smallest first: (A part, B part) = (wm', xs) (wh, xm) (wh, xh)
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {1, 2, 0};
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_f16(wa[PA[term]], xb[a][PB[term]], acc[a][b]);
+      } else if constexpr (NP == 3) {
         // six cross products, smallest first: (A part, B part) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); A = W, B = x
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -310,6 +320,18 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the prefetches issued past the end
 }
 
+// weights [N][K] fp32 -> the two f16 images [N][K] of the f16x3 form (wh, wm' = (w - wh) * 2^11)
+__global__ __launch_bounds__(256) void linear_pack_f16_kernel(const float* __restrict__ w, unsigned short* __restrict__ h,
+                                                              unsigned short* __restrict__ m, long long pairs) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (long long)gridDim.x * 256) {
+    const float2 v = reinterpret_cast<const float2*>(w)[i];
+    const f16x2v hh = __builtin_convertvector(f32x2{v.x, v.y}, f16x2v);
+    const f32x2 r = {(v.x - (float)hh[0]) * 2048.0f, (v.y - (float)hh[1]) * 2048.0f};
+    reinterpret_cast<unsigned*>(h)[i] = __builtin_bit_cast(unsigned, hh);
+    reinterpret_cast<unsigned*>(m)[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
+  }
+}
+
 // weights [N][K] fp32 -> three bf16 images [N][K]
 __global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ h,
                                                           unsigned short* __restrict__ m, unsigned short* __restrict__ l,
@@ -325,13 +347,13 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restric
 }
 
 
-template <int BN, int NP>
+template <int BN, int NP, bool F16 = false>
 static int32_t launch_v2(const Params& p, hipStream_t s) {
   // resident workgroups (2 per CU by LDS) of the CURRENT device, found once per device: hipFuncSetAttribute is per device too.
   // (atomic: concurrent first calls race benignly to the same value)
   static std::atomic<int> slots_of[64];
-  constexpr size_t lds = (size_t)NP * 8192 + 2 * (size_t)NP * BN * 64;
-  auto kern = linear_kernel<BN, NP>;
+  constexpr size_t lds = (size_t)NP * 8192 + 2 * (size_t)(F16 ? 2 : NP) * BN * 64;
+  auto kern = linear_kernel<BN, NP, F16>;
   int dev = 0;
   DLWP_HIP_CHECK(hipGetDevice(&dev));
   DLWP_REQUIRE(dev >= 0 && dev < 64, DLWP_ERR_UNSUPPORTED, "linear: device ordinal %d", dev);
@@ -355,11 +377,12 @@ static int32_t launch_v2(const Params& p, hipStream_t s) {
   return DLWP_OK;
 }
 
-// form 3: fp32-accurate (six products), 1: bf16 operands
+// form 3: fp32-accurate (six bf16 products), 2: fp32-grade f16x3 (three f16 products), 1: bf16 operands
 static int32_t launch(const Params& p, int form, hipStream_t s) {
   // 96-wide W tiles where 128 would waste a quarter or more of the last tile (N = 96, 192, 288, 576, 1152)
   const bool narrow = (p.N % 128) != 0 && (p.N % 128) <= 96 && (p.N % 96 == 0 || p.N < 128);
   if (form == 3) return narrow ? launch_v2<96, 3>(p, s) : launch_v2<128, 3>(p, s);
+  if (form == 2) return narrow ? launch_v2<96, 3, true>(p, s) : launch_v2<128, 3, true>(p, s);
   return narrow ? launch_v2<96, 1>(p, s) : launch_v2<128, 1>(p, s);
 }
 
@@ -387,6 +410,23 @@ extern "C" int32_t dlwp_linear_pack_f32(const float* weight_dev, int32_t out_fea
   hipLaunchKernelGGL(lin::linear_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      weight_dev, reinterpret_cast<unsigned short*>(b), reinterpret_cast<unsigned short*>(b + part),
                      reinterpret_cast<unsigned short*>(b + 2 * part), pairs);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_linear_pack_f16x3(const float* weight_dev, int32_t out_features, int32_t in_features, void* packed_dev,
+                                          void* stream) {
+  DLWP_REQUIRE(weight_dev && packed_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  const size_t bytes = dlwp_linear_packed_bytes(out_features, in_features);
+  DLWP_REQUIRE(bytes > 0, DLWP_ERR_UNSUPPORTED, "linear: in_features %d must be a multiple of 32, out_features %d of 4",
+               in_features, out_features);
+  const size_t part = bytes / 3;      // same buffer size as the bf16 images; the third part stays unused
+  char* b = reinterpret_cast<char*>(packed_dev);
+  const long long pairs = (long long)out_features * in_features / 2;
+  long long blocks = (pairs + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lin::linear_pack_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     weight_dev, reinterpret_cast<unsigned short*>(b), reinterpret_cast<unsigned short*>(b + part), pairs);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
@@ -423,4 +463,10 @@ extern "C" int32_t dlwp_linear_bf16(const float* x_dev, const void* packed_dev, 
                                     float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
                                     void* stream) {
   return linear_run(1, x_dev, packed_dev, bias_dev, resid_dev, out_dev, rows, in_features, out_features, act, stream);
+}
+
+extern "C" int32_t dlwp_linear_f16x3(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                                     float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
+                                     void* stream) {
+  return linear_run(2, x_dev, packed_dev, bias_dev, resid_dev, out_dev, rows, in_features, out_features, act, stream);
 }

@@ -97,6 +97,9 @@ SIGNATURES = {
                                   c_void_p]),
     "dlwp_linear_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32,
                                    c_void_p]),
+    "dlwp_linear_pack_f16x3": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "dlwp_linear_f16x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32,
+                                    c_void_p]),
     "dlwp_groupnorm_act_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
                                          c_int32, c_void_p]),
     "dlwp_conv2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

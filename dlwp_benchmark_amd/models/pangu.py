@@ -129,7 +129,7 @@ class _EarthSpecificBlock(nn.Module):
         if self.linear_form != "rocblas" and ops.attention_block_linears_supported(self.dim, self.mlp.fc1.out_features):
             # the four Linears as dlwp_linear_f32 (fp32-accurate GEMM on the bf16 pipe) or dlwp_linear_bf16, bias / GELU /
             # residual adds in their epilogues, in place on x
-            prec = "bf16" if self.linear_form == "bf16" else "fp32"
+            prec = ops.form_precision(self.linear_form)
             if pend is not None:
                 x.add_(pend)
             qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), self.attn.qkv,

@@ -93,7 +93,7 @@ class _Block(nn.Module):
         if self.linear_form != "rocblas" and ops.attention_block_linears_supported(self.dim, self.mlp.fc1.out_features):
             # the four Linears as dlwp_linear_f32 (fp32-accurate GEMM on the bf16 pipe) or dlwp_linear_bf16, bias / GELU /
             # residual adds in their epilogues, in place on x
-            prec = "bf16" if self.linear_form == "bf16" else "fp32"
+            prec = ops.form_precision(self.linear_form)
             if pend is not None:
                 x.add_(pend)
             qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), self.attn.qkv,
@@ -255,7 +255,7 @@ class SwinTransformer(HipBackbone):
         dec = None if (self.training and torch.is_grad_enabled()) else self._token_decoder()
         form = next((m.linear_form for m in self.modules() if hasattr(m, "linear_form")), "bf16x6")
         if dec is not None and form != "rocblas" and x.is_cuda:
-            return self._one_step_tokens(x, dec, "bf16" if form == "bf16" else "fp32")
+            return self._one_step_tokens(x, dec, ops.form_precision(form))
         x, h, w = self.patch_embed(x)
         outs = []
         for i, layer in enumerate(self.layers):

@@ -665,8 +665,16 @@ class LinearWeights:
     def __init__(self):
         self._key = None
         self._buf = None
+        self._f16 = None         # the f16x3 images live in a LinearWeights of their own (same derivation rule)
 
-    def get(self, weight: torch.Tensor) -> torch.Tensor:
+    def get(self, weight: torch.Tensor, f16: bool = False) -> torch.Tensor:
+        if f16:
+            if self._f16 is None:
+                self._f16 = LinearWeights()
+            return self._f16._get(weight, "dlwp_linear_pack_f16x3")
+        return self._get(weight, "dlwp_linear_pack_f32")
+
+    def _get(self, weight: torch.Tensor, packer: str) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, str(weight.device))
         if key != self._key:
             n, k = weight.shape
@@ -676,8 +684,8 @@ class LinearWeights:
                 raise _lib.DlwpError(f"linear: unsupported shape out={n} in={k} (need in % 32 == 0 and out % 4 == 0)")
             buf = torch.empty(nbytes // 4, dtype=torch.int32, device=weight.device)
             with torch.cuda.device(weight.device):
-                _lib.check(lib.dlwp_linear_pack_f32(weight.detach().contiguous().data_ptr(), n, k, buf.data_ptr(),
-                                                    _lib.stream_ptr()), "dlwp_linear_pack_f32")
+                _lib.check(getattr(lib, packer)(weight.detach().contiguous().data_ptr(), n, k, buf.data_ptr(),
+                                                _lib.stream_ptr()), packer)
             self._key, self._buf = key, buf
         return self._buf
 
@@ -686,10 +694,11 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
            out: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
     """act(x @ m.weight.T + m.bias) + resid over the last dimension in one launch; act 0 none / 1 exact GELU.
     precision "fp32": dlwp_linear_f32, fp32-accurate GEMM on the bf16 matrix pipe (six products of exact three-way splits);
-    "bf16": dlwp_linear_bf16, bf16 operands and fp32 accumulation (what autocast(bfloat16) makes of nn.Linear).
+    "bf16": dlwp_linear_bf16, bf16 operands and fp32 accumulation (what autocast(bfloat16) makes of nn.Linear);
+    "f16x3": dlwp_linear_f16x3, fp32-GEMM accuracy from exact two-part f16 splits (three products; |x| < 65504).
     `out` may be `resid` (in-place residual add).  With gradients wanted the torch operators run instead (training.py's
     convention)."""
-    if precision not in ("fp32", "bf16"):
+    if precision not in ("fp32", "bf16", "f16x3"):
         raise _lib.DlwpError(f"linear: unknown precision {precision!r}")
     from . import training as _T
     if _T.wants_grad(x, m.weight, m.bias, resid):
@@ -710,7 +719,7 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
     if cache is None:
         cache = LinearWeights()
         m.__dict__["_dlwp_packed"] = cache       # plain attribute: neither parameter nor buffer, not in the state dict
-    packed = cache.get(m.weight)
+    packed = cache.get(m.weight, f16=precision == "f16x3")
     shape = (*x.shape[:-1], n)
     if resid is not None:
         _lib.require_cuda_tensor(resid, "resid")
@@ -724,21 +733,28 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
         raise _lib.DlwpError("linear: out must not alias x")
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        fn = lib.dlwp_linear_bf16 if precision == "bf16" else lib.dlwp_linear_f32
-        _lib.check(fn(x.data_ptr(), packed.data_ptr(), m.bias.contiguous().data_ptr() if m.bias is not None else None,
-                      resid.data_ptr() if resid is not None else None, out.data_ptr(), x.numel() // k, k, n, int(act),
-                      _lib.stream_ptr()), "dlwp_linear_" + ("bf16" if precision == "bf16" else "f32"))
+        name = {"fp32": "dlwp_linear_f32", "bf16": "dlwp_linear_bf16", "f16x3": "dlwp_linear_f16x3"}[precision]
+        _lib.check(getattr(lib, name)(x.data_ptr(), packed.data_ptr(),
+                                      m.bias.contiguous().data_ptr() if m.bias is not None else None,
+                                      resid.data_ptr() if resid is not None else None, out.data_ptr(), x.numel() // k, k, n,
+                                      int(act), _lib.stream_ptr()), name)
     return out
 
 
-LINEAR_FORMS = ("bf16x6", "bf16", "rocblas")
+LINEAR_FORMS = ("bf16x6", "f16x3", "bf16", "rocblas")
+_FORM_PRECISION = {"bf16x6": "fp32", "f16x3": "f16x3", "bf16": "bf16"}
+
+
+def form_precision(form: str) -> str:
+    """the `precision` argument of linear() a model's linear_form stands for"""
+    return _FORM_PRECISION[form]
 
 
 def linear_as(form: str, x: torch.Tensor, m: torch.nn.Linear) -> torch.Tensor:
     """m(x) through dlwp_linear_f32 (form "bf16x6") / dlwp_linear_bf16 ("bf16") when the shape is covered, else the module
     itself (rocBLAS fp32)."""
-    if form in ("bf16x6", "bf16") and x.is_cuda and linear_supported(m.in_features, m.out_features):
-        return linear(x, m, precision="bf16" if form == "bf16" else "fp32")
+    if form in _FORM_PRECISION and x.is_cuda and linear_supported(m.in_features, m.out_features):
+        return linear(x, m, precision=_FORM_PRECISION[form])
     return m(x)
 
 

@@ -330,6 +330,15 @@ int32_t dlwp_linear_f32(const float* x_dev, const void* packed_dev, const float*
  * accumulation -- what torch.autocast(bfloat16) makes of nn.Linear; one matrix-pipe product instead of six. */
 int32_t dlwp_linear_bf16(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
                          float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act, void* stream);
+/* The same Linear in the "f16x3" form: both operands split exactly into two f16 parts (22 significant bits; the weight
+ * residual stored scaled by 2^11, so any weight magnitude keeps them), three products on the f16 matrix instructions
+ * instead of six bf16 ones.  fp32-GEMM accuracy for |x| < 65504 (an x beyond the f16 range turns into inf: the caller's
+ * contract; LayerNorm / GELU / attention outputs are orders of magnitude inside it) and for activations that are not
+ * all tiny (the residual of |x| < 0.125 is an f16 subnormal, absolute spacing 2^-24).  `packed_dev` comes from
+ * dlwp_linear_pack_f16x3 (same byte count as dlwp_linear_packed_bytes). */
+int32_t dlwp_linear_pack_f16x3(const float* weight_dev, int32_t out_features, int32_t in_features, void* packed_dev, void* stream);
+int32_t dlwp_linear_f16x3(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                          float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The remaining U-Net / ModernUNet operators (csrc/conv2.hip), NCHW fp32, activations as above.

@@ -46,6 +46,50 @@ def test_linear_matches_float64(rows, k, n, bias, act, resid):
     assert (got.double() - want).abs().max() <= 2e-5 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,k,n,bias,act,resid,wgain", [
+    (1000, 96, 288, True, 0, False, 3.0), (77, 96, 96, True, 0, True, 3.0), (4096, 96, 384, True, 1, False, 3.0),
+    (4096, 384, 96, True, 0, True, 1e-3), (2051, 192, 576, True, 0, False, 3.0), (513, 768, 192, True, 0, True, 3.0),
+    (300, 32, 100, False, 1, True, 3.0), (9000, 384, 1536, True, 1, False, 30.0), (1, 1536, 384, False, 0, True, 3.0)])
+def test_linear_f16x3_matches_float64(rows, k, n, bias, act, resid, wgain):
+    """dlwp_linear_f16x3 (precision "f16x3"): the same operator from exact two-part f16 splits (three products).  Same
+    fp32-GEMM bound as dlwp_linear_f32 against float64, at weight magnitudes three orders apart (the scaled weight residual
+    keeps 22 bits at any of them); inputs are O(1) like the LayerNorm / GELU / attention outputs the blocks feed it."""
+    from dlwp_benchmark_amd import ops
+
+    torch.manual_seed(rows + k)
+    m = torch.nn.Linear(k, n, bias=bias)
+    with torch.no_grad():
+        m.weight.mul_(wgain)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, k, generator=g) * 2.0 + 0.3).to(DEV)
+    r = torch.randn(rows, n, generator=g).to(DEV) if resid else None
+    with torch.no_grad():
+        got = ops.linear(x, m, act=act, resid=r, precision="f16x3")
+        ref32 = ops.linear(x, m, act=act, resid=r)
+        want = F.linear(x.double(), m.weight.double(), m.bias.double() if bias else None)
+        if act:
+            want = F.gelu(want)
+        if resid:
+            want = want + r.double()
+    assert got.shape == want.shape
+    assert rel_l2(got, want) <= 1e-6, (rel_l2(got, want), rel_l2(ref32, want))
+    assert (got.double() - want).abs().max() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_linear_f16x3_weight_cache_follows_the_parameter():
+    from dlwp_benchmark_amd import ops
+
+    m = _linear(96, 96, True, seed=5)
+    x = torch.randn(256, 96, device=DEV)
+    with torch.no_grad():
+        a = ops.linear(x, m, precision="f16x3")
+        m.weight.mul_(2.0)
+        b = ops.linear(x, m, precision="f16x3")
+        want = F.linear(x.double(), m.weight.double(), m.bias.double())
+    assert rel_l2(b, want) <= 1e-6 and rel_l2(a, want) > 1e-2
+
+
 @pytest.mark.parametrize("rows,k,n,act,resid", [(1000, 96, 288, 0, False), (4096, 384, 96, 0, True), (2051, 192, 768, 1, False),
                                                  (300, 32, 100, 1, True)])
 def test_linear_bf16_matches_bf16_rounded_operands(rows, k, n, act, resid):

@@ -38,7 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring of the shape label")
-    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"))
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16", "f16x3"))
     args = ap.parse_args()
     dev = "cuda:0"
     print(f"{'shape':18s} {'rows':>8s} {'in':>5s} {'out':>5s} | {'hip us':>8s} {'TF/s(6x)':>9s} | {'torch us':>9s} | err hip / torch")
