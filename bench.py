@@ -199,7 +199,8 @@ def bench_other_configs(device, only=None, reps=2):
         # "bf16": bf16 window attention only; "bf16all": bf16 attention AND bf16 Linear operands (the autocast(bfloat16)
         # analogue BASELINE configs[2] names); fp32 accumulation, LayerNorm and residual stream in all of them
         # "f16x3": fp32 attention, the Linears in the fp32-grade f16x3 form (two-part f16 splits, three products)
-        variants = ["fp32"] + (["f16x3", "bf16", "bf16all"] if cls in ("SwinTransformer", "PanguWeather") else [])
+        variants = ["fp32"] + (["f16x3", "bf16", "bf16all"] if cls in ("SwinTransformer", "PanguWeather") else []) + \
+            (["f16x3"] if cls == "FourCastNet" else [])
         model = getattr(M, cls)(**cfg)
         sha = fill_state_dict(model, gain=gain)
         model = model.to(device).eval()
@@ -226,8 +227,11 @@ def bench_other_configs(device, only=None, reps=2):
             if hasattr(model, "set_attention_precision"):
                 model.set_attention_precision(prec)
                 model.set_linear_form({"bf16all": "bf16", "f16x3": "f16x3"}.get(variant, "bf16x6"))
+            if hasattr(model, "set_mlp_form"):
+                model.set_mlp_form("f16x3" if variant == "f16x3" else "bf16x6")
             what = {"fp32": "fp32", "bf16": "bf16 window attention (fp32 elsewhere)",
-                    "f16x3": "fp32 (Linear products from exact two-part f16 splits, dlwp_linear_f16x3; fp32-accurate attention)",
+                    "f16x3": "fp32 (block-tail MLP products from exact two-part f16 splits, dlwp_afno_block_tail_f16x3)" if cls == "FourCastNet"
+                             else "fp32 (Linear products from exact two-part f16 splits, dlwp_linear_f16x3; fp32-accurate attention)",
                     "bf16all": "bf16 window attention and bf16 Linear operands (fp32 accumulation, LayerNorm, residual stream)"}[variant]
             entry = {"workload": f"{cls} {h}x{w}, {cfg['prognostic_channels']} prognostic ch, {steps}-step rollout, {what}",
                      "batch": batch, "rollout_steps": steps, "weights": "deterministic filler sha256:" + sha[:16],
@@ -319,7 +323,8 @@ def _other_roofline(cls, cfg, batch, h, w, summ, prec):
                 "pipe": "bf16 MFMA (dense peak)" if prec == "bf16" else "fp32-accurate form priced against the fp32 matrix peak"}
     if cls == "FourCastNet":
         c, hid = cfg["embed_dim"], int(cfg["embed_dim"] * cfg["mlp_ratio"])
-        tail = [(k, v) for k, v in summ.items() if k[0] in ("dlwp_afno_block_tail_f32", "dlwp_token_mlp_f32", "dlwp_token_mlp_emit_norm_f32")]
+        tail = [(k, v) for k, v in summ.items() if k[0] in ("dlwp_afno_block_tail_f32", "dlwp_afno_block_tail_f16x3", "dlwp_token_mlp_f32",
+                                                            "dlwp_token_mlp_emit_norm_f32")]
         if not tail:
             return None
         tot = sum(v["total_ms"] for _, v in tail)

@@ -56,13 +56,25 @@ __host__ __device__ inline size_t n_w2l(int hid, int OT) { return (size_t)(hid /
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ b1, unsigned* __restrict__ dst, int C,
-                                                   int hid, int merged_layout) {
+                                                   int hid, int merged_layout, int f16) {
   const int KS = C / 32, OT = C / 16;
   unsigned* w1hm = dst;
   unsigned* w2hm = w1hm + n_w1hm(hid, KS) * 4;
   unsigned* w1l = w2hm + n_w2hm(hid, OT) * 4;
   unsigned* w2l = w1l + n_w1l(hid, KS) * 4;
   const int n1 = (hid / 16) * KS * 64 * 4, n2 = (hid / 32) * OT * 64 * 4;
+  // f16: the "f16x3" images (common.hpp) -- h = f16(w), m = f16((w - h) * 2^11), no third part
+  auto split = [&](float a, float b, unsigned& h, unsigned& m, unsigned& lo) {
+    if (f16) {
+      const f16x2v hh = __builtin_convertvector(f32x2{a, b}, f16x2v);
+      const f32x2 r = {(a - (float)hh[0]) * 2048.0f, (b - (float)hh[1]) * 2048.0f};
+      h = __builtin_bit_cast(unsigned, hh);
+      m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
+      lo = 0u;
+    } else {
+      split3_pair(a, b, h, m, lo);
+    }
+  };
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
     unsigned h, m, lo;
     if (i < n1) {
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
       const int e0 = 2 * d;
       const int ch = merged_layout ? 16 * (2 * ks + e0 / 4) + 4 * (l >> 4) + e0 % 4 : 32 * ks + 8 * (l >> 4) + e0;
       const float* src = w1 + (size_t)(16 * t + (l & 15)) * C + ch;
-      split3_pair(gamma ? src[0] * gamma[ch] : src[0], gamma ? src[1] * gamma[ch + 1] : src[1], h, m, lo);
+      split(gamma ? src[0] * gamma[ch] : src[0], gamma ? src[1] * gamma[ch + 1] : src[1], h, m, lo);
       w1hm[((size_t)(tk * 2 + 0) * 64 + l) * 4 + d] = h;
       w1hm[((size_t)(tk * 2 + 1) * 64 + l) * 4 + d] = m;
       w1l[((size_t)tk * 64 + l) * 4 + d] = lo;
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
       const int u = uo / OT, ot = uo % OT, g = l >> 4, jj = 2 * d;
       const int ch = 16 * (2 * u + jj / 4) + 4 * g + jj % 4;
       const float* src = w2 + (size_t)(16 * ot + (l & 15)) * hid + ch;
-      split3_pair(src[0], src[1], h, m, lo);
+      split(src[0], src[1], h, m, lo);
       w2hm[((size_t)((u * 2 + 0) * OT + ot) * 64 + l) * 4 + d] = h;
       w2hm[((size_t)((u * 2 + 1) * OT + ot) * 64 + l) * 4 + d] = m;
       w2l[((size_t)uo * 64 + l) * 4 + d] = lo;
@@ -104,7 +116,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
 __device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
 
-template <int KS, int OT, bool RESID, bool LN, bool NEXT, bool MERGE = false>
+// F16: the f16x3 product form (common.hpp) -- B operands (xh, xh * 2^-11, xm), A operands the two LDS-resident images
+// (wh, wm'), three products per accumulator; the third weight image and its global loads do not exist.
+__device__ constexpr int kPA16[3] = {1, 0, 0};
+__device__ constexpr int kPB16[3] = {1, 2, 0};
+
+template <int KS, int OT, bool RESID, bool LN, bool NEXT, bool MERGE = false, bool F16 = false>
 __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   constexpr int C = 32 * KS;
   static_assert(OT * 16 == C, "square MLP");
@@ -164,12 +181,14 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   // pass requests unit 0's again), so each load has most of a unit to land.
   u32x4 wl1[2][KS], wl2[OT];
   auto load_lo1 = [&](int u) {
+    if constexpr (F16) return;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) wl1[tt][ks] = p.w1l[((2 * u + tt) * KS + ks) * 64 + lane];
   };
   auto load_lo2 = [&](int u) {
+    if constexpr (F16) return;
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) wl2[ot] = p.w2l[(u * OT + ot) * 64 + lane];
   };
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {   // k-slots 2i, 2i+1 of k-step ks = channels 16 (2 ks + i / 2) + 4 g + 2 (i % 2), + 1
             unsigned hh, mm, ll;
-            split3_pair(sv[2 * ks + i / 2][2 * (i % 2)] * rstd, sv[2 * ks + i / 2][2 * (i % 2) + 1] * rstd, hh, mm, ll);
+            split_pair_x<F16>(sv[2 * ks + i / 2][2 * (i % 2)] * rstd, sv[2 * ks + i / 2][2 * (i % 2) + 1] * rstd, hh, mm, ll);
             bx[q][ks][0][i] = hh;
             bx[q][ks][1][i] = mm;
             bx[q][ks][2][i] = ll;
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             unsigned hh, mm, ll;
-            split3_pair(v[ks][i / 2][2 * (i % 2)], v[ks][i / 2][2 * (i % 2) + 1], hh, mm, ll);
+            split_pair_x<F16>(v[ks][i / 2][2 * (i % 2)], v[ks][i / 2][2 * (i % 2) + 1], hh, mm, ll);
             bx[q][ks][0][i] = hh;
             bx[q][ks][1][i] = mm;
             bx[q][ks][2][i] = ll;
@@ -342,8 +361,17 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
           const int tk = (2 * u + tt) * KS + ks;
           wa[tt][0] = s_w1[(tk * 2 + 0) * 64 + lane];
           wa[tt][1] = s_w1[(tk * 2 + 1) * 64 + lane];
-          wa[tt][2] = wl1[tt][ks];
+          if constexpr (!F16) wa[tt][2] = wl1[tt][ks];
         }
+        if constexpr (F16) {
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                a1[tt][q] = mfma16x16x32_f16(wa[tt][kPA16[term]], bx[q][ks][kPB16[term]], a1[tt][q]);
+        } else {
 #pragma unroll
         for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -351,6 +379,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
               a1[tt][q] = mfma16x16x32_bf16(wa[tt][kPA[term]], bx[q][ks][kPB[term]], a1[tt][q]);
+        }
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -364,7 +393,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {   // dword i: k-slots 2i, 2i+1 -> tile i/2, registers 2(i%2), 2(i%2)+1
           unsigned hh, mm, ll;
-          split3_pair(a1[i / 2][q][2 * (i % 2)], a1[i / 2][q][2 * (i % 2) + 1], hh, mm, ll);
+          split_pair_x<F16>(a1[i / 2][q][2 * (i % 2)], a1[i / 2][q][2 * (i % 2) + 1], hh, mm, ll);
           bg[q][0][i] = hh;
           bg[q][1][i] = mm;
           bg[q][2][i] = ll;
@@ -378,8 +407,17 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
         for (int oo = 0; oo < 2; ++oo) {
           wb[oo][0] = s_w2[((u * 2 + 0) * OT + oh + oo) * 64 + lane];
           wb[oo][1] = s_w2[((u * 2 + 1) * OT + oh + oo) * 64 + lane];
-          wb[oo][2] = wl2[oh + oo];
+          if constexpr (!F16) wb[oo][2] = wl2[oh + oo];
         }
+        if constexpr (F16) {
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int oo = 0; oo < 2; ++oo)
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                acc2[oh + oo][q] = mfma16x16x32_f16(wb[oo][kPA16[term]], bg[q][kPB16[term]], acc2[oh + oo][q]);
+        } else {
 #pragma unroll
         for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -387,6 +425,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
               acc2[oh + oo][q] = mfma16x16x32_bf16(wb[oo][kPA[term]], bg[q][kPB[term]], acc2[oh + oo][q]);
+        }
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -462,25 +501,38 @@ extern "C" size_t dlwp_token_mlp_packed_bytes(int32_t channels, int32_t hidden) 
          (size_t)hidden * 4;   // + the folded fc1 bias of the LayerNorm variant
 }
 
-extern "C" int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
-                                           const float* ln_beta_dev, const float* b1_dev, int32_t channels,
-                                           int32_t hidden, int32_t merged_layout, void* packed_dev, void* stream) {
+static int32_t token_mlp_pack(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
+                              const float* ln_beta_dev, const float* b1_dev, int32_t channels,
+                              int32_t hidden, int32_t merged_layout, void* packed_dev, void* stream, int f16) {
   DLWP_REQUIRE(w1_dev && w2_dev && packed_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE((ln_gamma_dev == nullptr) == (ln_beta_dev == nullptr), DLWP_ERR_INVALID_ARGUMENT,
                "LayerNorm weight and bias must be given together");
   DLWP_REQUIRE(token_mlp_shape_ok(channels, hidden, nullptr), DLWP_ERR_UNSUPPORTED,
                "token MLP: channels %d (64 supported), hidden %d (multiple of 64, <= 256: weights must fit LDS)", channels, hidden);
   hipLaunchKernelGGL(tmlp::pack_kernel, dim3(64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w1_dev, w2_dev,
-                     ln_gamma_dev, ln_beta_dev, b1_dev, reinterpret_cast<unsigned*>(packed_dev), channels, hidden, merged_layout ? 1 : 0);
+                     ln_gamma_dev, ln_beta_dev, b1_dev, reinterpret_cast<unsigned*>(packed_dev), channels, hidden, merged_layout ? 1 : 0,
+                     f16);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_token_mlp_pack_f32(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
+                                           const float* ln_beta_dev, const float* b1_dev, int32_t channels,
+                                           int32_t hidden, int32_t merged_layout, void* packed_dev, void* stream) {
+  return token_mlp_pack(w1_dev, w2_dev, ln_gamma_dev, ln_beta_dev, b1_dev, channels, hidden, merged_layout, packed_dev, stream, 0);
+}
+
+extern "C" int32_t dlwp_token_mlp_pack_f16x3(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
+                                             const float* ln_beta_dev, const float* b1_dev, int32_t channels,
+                                             int32_t hidden, int32_t merged_layout, void* packed_dev, void* stream) {
+  return token_mlp_pack(w1_dev, w2_dev, ln_gamma_dev, ln_beta_dev, b1_dev, channels, hidden, merged_layout, packed_dev, stream, 1);
 }
 
 static int32_t token_mlp_impl(const float* n_dev, const float* resid_dev, const void* packed_dev, const float* b1_dev,
                               const float* b2_dev, float* out_dev, int64_t tokens, int32_t channels, int32_t hidden,
                               float ln_eps, const float* next_gamma_dev, const float* next_beta_dev, float next_eps,
                               float* next_cf_dev, int64_t tokens_per_sample, void* stream,
-                              const float* f_cf_dev = nullptr, const float* l_cf_dev = nullptr) {
+                              const float* f_cf_dev = nullptr, const float* l_cf_dev = nullptr, bool f16 = false) {
   const bool ln = ln_eps >= 0.f;
   const bool next = next_cf_dev != nullptr;
   const bool merge = f_cf_dev != nullptr;
@@ -545,6 +597,10 @@ static int32_t token_mlp_impl(const float* n_dev, const float* resid_dev, const 
   }
 #undef DLWP_TM
   if (merge) kern = next ? tmlp::token_mlp_kernel<2, 4, true, true, true, true> : tmlp::token_mlp_kernel<2, 4, true, true, false, true>;
+  if (f16) {
+    DLWP_REQUIRE(merge, DLWP_ERR_UNSUPPORTED, "token MLP: the f16x3 form exists for the merged block tail only");
+    kern = next ? tmlp::token_mlp_kernel<2, 4, true, true, true, true, true> : tmlp::token_mlp_kernel<2, 4, true, true, false, true, true>;
+  }
   DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   DLWP_HIP_CHECK(hipGetLastError());
@@ -592,4 +648,16 @@ extern "C" int32_t dlwp_afno_block_tail_f32(const float* f_cf_dev, const float* 
   return token_mlp_impl(x_nhwc_dev, x_nhwc_dev, packed_dev, nullptr, b2_dev, out_nhwc_dev, (int64_t)batch * tokens_per_sample,
                         channels, hidden, ln_eps, next_gamma_dev, next_beta_dev, next_eps, next_cf_dev, tokens_per_sample,
                         stream, f_cf_dev, l_cf_dev);
+}
+
+extern "C" int32_t dlwp_afno_block_tail_f16x3(const float* f_cf_dev, const float* l_cf_dev, const float* x_nhwc_dev,
+                                              const void* packed_dev, const float* b2_dev, float* out_nhwc_dev,
+                                              int32_t batch, int64_t tokens_per_sample, int32_t channels, int32_t hidden,
+                                              float ln_eps, const float* next_gamma_dev, const float* next_beta_dev,
+                                              float next_eps, float* next_cf_dev, void* stream) {
+  DLWP_REQUIRE(f_cf_dev && l_cf_dev && x_nhwc_dev && out_nhwc_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0 && ln_eps >= 0.f, DLWP_ERR_INVALID_ARGUMENT, "bad arguments");
+  return token_mlp_impl(x_nhwc_dev, x_nhwc_dev, packed_dev, nullptr, b2_dev, out_nhwc_dev, (int64_t)batch * tokens_per_sample,
+                        channels, hidden, ln_eps, next_gamma_dev, next_beta_dev, next_eps, next_cf_dev, tokens_per_sample,
+                        stream, f_cf_dev, l_cf_dev, /*f16=*/true);
 }

@@ -126,6 +126,10 @@ SIGNATURES = {
                                           c_void_p]),
     "dlwp_afno_block_tail_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64,
                                            c_int32, c_int32, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "dlwp_token_mlp_pack_f16x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
+                                            c_void_p]),
+    "dlwp_afno_block_tail_f16x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64,
+                                             c_int32, c_int32, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dlwp_token_mlp_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32,
                                      c_int32, c_float, c_void_p]),
     "dlwp_token_mlp_emit_norm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64,
@@ -208,7 +212,7 @@ class KernelTimer:
         import torch
 
         lib = load()
-        names = self.names or [n for n in SIGNATURES if n.endswith(("_f32", "_bf16"))]
+        names = self.names or [n for n in SIGNATURES if n.endswith(("_f32", "_bf16", "_f16x3"))]
         for name in names:
             fn = getattr(lib, name)
             self._saved[name] = fn

@@ -62,6 +62,7 @@ class _Block(nn.Module):
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self._mlp_packed = ops.TokenMlpWeights()   # derived operand layout, not part of the state dict
         self._mlp_fused = None
+        self.mlp_form = "bf16x6"                   # or "f16x3": the block tail's products from two-part f16 splits (FourCastNet.set_mlp_form)
 
     def forward(self, x, l_cf=None, next_norm=None):
         """fourcastnet.py:180-193 (double skip).  LayerNorm1 writes channels-first for the FFT; the inverse
@@ -89,9 +90,9 @@ class _Block(nn.Module):
                 # `+ bias`, first skip, LayerNorm2, fc1 -> GELU -> fc2, second skip (:127, :187, :191-192) and the next
                 # block's norm1 in ONE launch, in place on x (norm2's affine part lives in the packed fc1 operands)
                 packed = self._mlp_packed.get(m.fc1.weight, m.fc2.weight, self.norm2.weight, self.norm2.bias, m.fc1.bias,
-                                              merged=True)
+                                              merged=True, f16x3=self.mlp_form == "f16x3")
                 res = ops.afno_block_tail(f_cf, l_cf, x, packed, m.fc2.bias, m.fc1.out_features, self.norm2.eps,
-                                          emit_norm=emit, out=x if x.is_contiguous() else None)
+                                          emit_norm=emit, out=x if x.is_contiguous() else None, form=self.mlp_form)
                 return res if emit is not None else (res, None)
             # odd token counts: merge kernel (sum only) + token MLP with LayerNorm2 fused
             s, _ = ops.afno_merge(f_cf, l_cf, x, None, None, self.norm2.eps, want_norm=False)
@@ -140,6 +141,16 @@ class FourCastNet(HipBackbone):
                                             hard_thresholding_fraction) for _ in range(depth)])
         self.norm = ops.HipLayerNorm(embed_dim, eps=1e-6)   # in the reference state dict, never applied (:283-293)
         self.head = nn.Linear(embed_dim, self.out_chans * self.patch_size[0] * self.patch_size[1], bias=False)
+
+    def set_mlp_form(self, form: str):
+        """"bf16x6" (default): the block tails' fp32 products from three-part bf16 splits (six matrix instructions each);
+        "f16x3": from two-part f16 splits (three) -- dlwp_afno_block_tail_f16x3.  Both fp32-GEMM accurate.  Per-module state."""
+        if form not in ("bf16x6", "f16x3"):
+            raise _lib.DlwpError(f"unknown MLP form {form!r}")
+        for m in self.modules():
+            if hasattr(m, "mlp_form"):
+                m.mlp_form = form
+        return self
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:
         b = x.shape[0]

@@ -536,10 +536,12 @@ class TokenMlpWeights:
         self._buf = None
 
     def get(self, w1: torch.Tensor, w2: torch.Tensor, ln_weight: Optional[torch.Tensor] = None,
-            ln_bias: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None, merged: bool = False) -> torch.Tensor:
-        """merged=True: the k-slot order afno_block_tail wants (a different permutation of W1's columns)."""
+            ln_bias: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None, merged: bool = False,
+            f16x3: bool = False) -> torch.Tensor:
+        """merged=True: the k-slot order afno_block_tail wants (a different permutation of W1's columns);
+        f16x3=True: the two f16 images of the f16x3 product form (afno_block_tail(form="f16x3"))."""
         extra = [t for t in (ln_weight, ln_bias, b1) if t is not None]
-        key = tuple((t.data_ptr(), t._version) for t in (w1, w2, *extra)) + (str(w1.device), ln_weight is not None, merged)
+        key = tuple((t.data_ptr(), t._version) for t in (w1, w2, *extra)) + (str(w1.device), ln_weight is not None, merged, f16x3)
         if key != self._key:
             hid, c = w1.shape
             if tuple(w2.shape) != (c, hid):
@@ -556,9 +558,9 @@ class TokenMlpWeights:
                 return t.detach().contiguous().data_ptr() if t is not None else None
 
             with torch.cuda.device(w1.device):
-                _lib.check(lib.dlwp_token_mlp_pack_f32(ptr(w1), ptr(w2), ptr(ln_weight), ptr(ln_bias), ptr(b1), c, hid,
-                                                       1 if merged else 0, buf.data_ptr(), _lib.stream_ptr()),
-                           "dlwp_token_mlp_pack_f32")
+                packer = "dlwp_token_mlp_pack_f16x3" if f16x3 else "dlwp_token_mlp_pack_f32"
+                _lib.check(getattr(lib, packer)(ptr(w1), ptr(w2), ptr(ln_weight), ptr(ln_bias), ptr(b1), c, hid,
+                                                1 if merged else 0, buf.data_ptr(), _lib.stream_ptr()), packer)
             self._key, self._buf = key, buf
         return self._buf
 
@@ -605,11 +607,16 @@ def token_mlp(n: torch.Tensor, resid: Optional[torch.Tensor], packed: torch.Tens
 
 
 def afno_block_tail(f_cf: torch.Tensor, l_cf: torch.Tensor, x_nhwc: torch.Tensor, packed: torch.Tensor,
-                    b2: Optional[torch.Tensor], hidden: int, ln_eps: float, emit_norm=None, out: Optional[torch.Tensor] = None):
+                    b2: Optional[torch.Tensor], hidden: int, ln_eps: float, emit_norm=None, out: Optional[torch.Tensor] = None,
+                    form: str = "bf16x6"):
     """Everything of an AFNO block after the inverse FFT, one launch (fourcastnet.py:127, :187, :191-192):
     sum = f_cf + l_cf + x;  out = sum + fc2(gelu(fc1(LayerNorm(sum)))).  f_cf / l_cf [B, C, H, W], x / out [B, H, W, C];
     packed = TokenMlpWeights.get(..., norm2.weight, norm2.bias, fc1.bias, merged=True).
-    emit_norm = (weight, bias, eps) of the next block's norm1 -> returns (out, LayerNorm(out) [B, C, H, W])."""
+    emit_norm = (weight, bias, eps) of the next block's norm1 -> returns (out, LayerNorm(out) [B, C, H, W]).
+    form "bf16x6" (three-part bf16 splits, six products) or "f16x3" (two-part f16 splits, three products; `packed` must
+    come from TokenMlpWeights.get(..., f16x3=True)) -- both fp32-GEMM accurate, the operands here are LayerNorm / GELU outputs."""
+    if form not in ("bf16x6", "f16x3"):
+        raise _lib.DlwpError(f"afno_block_tail: unknown form {form!r}")
     for t, nm in ((f_cf, "f_cf"), (l_cf, "l_cf"), (x_nhwc, "x")):
         _lib.require_cuda_tensor(t, nm)
     f_cf, l_cf, x_nhwc = f_cf.contiguous(), l_cf.contiguous(), x_nhwc.contiguous()
@@ -622,13 +629,14 @@ def afno_block_tail(f_cf: torch.Tensor, l_cf: torch.Tensor, x_nhwc: torch.Tensor
     gamma, beta, eps = emit_norm if emit_norm is not None else (None, None, 0.0)
     lib = _lib.load()
     with torch.cuda.device(x_nhwc.device):
-        _lib.check(lib.dlwp_afno_block_tail_f32(f_cf.data_ptr(), l_cf.data_ptr(), x_nhwc.data_ptr(), packed.data_ptr(),
+        name = "dlwp_afno_block_tail_f16x3" if form == "f16x3" else "dlwp_afno_block_tail_f32"
+        _lib.check(getattr(lib, name)(f_cf.data_ptr(), l_cf.data_ptr(), x_nhwc.data_ptr(), packed.data_ptr(),
                                                 b2.contiguous().data_ptr() if b2 is not None else None, out.data_ptr(), b,
                                                 h * w, c, int(hidden), float(ln_eps),
                                                 gamma.contiguous().data_ptr() if gamma is not None else None,
                                                 beta.contiguous().data_ptr() if beta is not None else None, float(eps),
                                                 nxt.data_ptr() if nxt is not None else None, _lib.stream_ptr()),
-                   "dlwp_afno_block_tail_f32")
+                   name)
     return (out, nxt) if emit_norm is not None else out
 
 

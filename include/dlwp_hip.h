@@ -469,6 +469,18 @@ int32_t dlwp_afno_block_tail_f32(const float* f_cf_dev, const float* l_cf_dev, c
                                  int64_t tokens_per_sample, int32_t channels, int32_t hidden, float ln_eps,
                                  const float* next_gamma_dev, const float* next_beta_dev, float next_eps,
                                  float* next_cf_dev, void* stream);
+/* The same block tail in the "f16x3" product form (exact two-part f16 splits of both operands, three products on the f16
+ * matrix instructions instead of six bf16 ones; both weight images fit the LDS, nothing is re-read from global memory).
+ * packed_dev from dlwp_token_mlp_pack_f16x3 (same arguments and byte count as dlwp_token_mlp_pack_f32).  fp32-GEMM
+ * accuracy; its operands are LayerNorm and GELU outputs, orders of magnitude inside the f16 range. */
+int32_t dlwp_token_mlp_pack_f16x3(const float* w1_dev, const float* w2_dev, const float* ln_gamma_dev,
+                                  const float* ln_beta_dev, const float* b1_dev, int32_t channels, int32_t hidden,
+                                  int32_t merged_layout, void* packed_dev, void* stream);
+int32_t dlwp_afno_block_tail_f16x3(const float* f_cf_dev, const float* l_cf_dev, const float* x_nhwc_dev,
+                                   const void* packed_dev, const float* b2_dev, float* out_nhwc_dev, int32_t batch,
+                                   int64_t tokens_per_sample, int32_t channels, int32_t hidden, float ln_eps,
+                                   const float* next_gamma_dev, const float* next_beta_dev, float next_eps,
+                                   float* next_cf_dev, void* stream);
 
 /* On-device evaluation sums (reference scripts/evaluate.py:786-821 `compute_metrics` + the
  * de-normalisation of :281-296): out_dev, target_dev [B, K, C, H, W]; climatology_dev [K, C, H, W] or NULL;

@@ -100,10 +100,12 @@ def test_token_mlp_emits_next_layernorm_channels_first():
     assert rel_l2(nxt, ref_kernel) < 1e-6
 
 
+@pytest.mark.parametrize("form", ["bf16x6", "f16x3"])
 @pytest.mark.parametrize("emit", [False, True])
-def test_afno_block_tail_matches_fp64(emit):
-    """dlwp_afno_block_tail_f32 = `+ bias`, first skip, norm2, Mlp, second skip (+ the next block's norm1) of the AFNO
-    block (fourcastnet.py:127, :187, :191-192, :182) against the same expression in float64."""
+def test_afno_block_tail_matches_fp64(emit, form):
+    """dlwp_afno_block_tail_f32 / _f16x3 = `+ bias`, first skip, norm2, Mlp, second skip (+ the next block's norm1) of the
+    AFNO block (fourcastnet.py:127, :187, :191-192, :182) against the same expression in float64 -- the same bound for the
+    three-part bf16 and the two-part f16 product form."""
     from dlwp_benchmark_amd import ops
 
     dev = torch.device("cuda:0")
@@ -123,9 +125,10 @@ def test_afno_block_tail_matches_fp64(emit):
     s64 = (f_cf + l_cf).double().permute(0, 2, 3, 1) + x.double()
     n64 = torch.nn.functional.layer_norm(s64, (c,), g2.double(), be2.double(), eps)
     want = _reference(n64, s64, w1, b1, w2, b2)
-    packed = ops.TokenMlpWeights().get(w1, w2, g2, be2, b1, merged=True)
+    packed = ops.TokenMlpWeights().get(w1, w2, g2, be2, b1, merged=True, f16x3=form == "f16x3")
     xin = x.clone()
-    res = ops.afno_block_tail(f_cf, l_cf, xin, packed, b2, hidden, eps, emit_norm=(g1, be1, eps) if emit else None, out=xin)
+    res = ops.afno_block_tail(f_cf, l_cf, xin, packed, b2, hidden, eps, emit_norm=(g1, be1, eps) if emit else None, out=xin,
+                              form=form)
     out = res[0] if emit else res
     assert out.data_ptr() == xin.data_ptr()
     assert rel_l2(out, want) < 2e-6
