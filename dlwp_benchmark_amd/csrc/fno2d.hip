@@ -1179,6 +1179,8 @@ struct TrunkParams {
   const float* r_prog;     // prognostic [B, T, n_prog, H, W]
   float* r_out;            // out        [B, T - ctx, n_prog, H, W]
   int r_nconst, r_npresc, r_nprog, r_T, r_ctx, r_t0;   // first time index of this launch (ctx + step_begin)
+  int feed_regs;           // n_steps > 1, no constants / prescribed channels, context 1, <= 4 prognostic channels: a step's whole
+                           // input (and its residual) is the output the SAME lanes have just computed -- it stays in registers
   int n_steps;             // 0 / 1: one step described by in / out / resid
   // hand-off bounds (plan knobs): polls of a counter barrier / re-loads of a flag-in-data block before the workgroup
   // gives up; a workgroup that gives up poisons its outputs with NaN AND sets *fail_word (checked by the host)
@@ -1408,6 +1410,12 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   // is what the same wave has just written, so steps need no synchronisation beyond the spectrum hand-offs)
   int n_stamp = 0;
   const int n_steps = (STEP && p.n_steps > 1) ? p.n_steps : 1;
+  f32x4 vfeed = {0.f, 0.f, 0.f, 0.f};   // feed_regs: the previous step's output of this lane (channel g, pixels 4j..4j+3)
+  // the lifting weights of the NEXT step are requested before the end-of-step barrier and written to LDS behind it
+  // (staged = they are already there when the step starts)
+  u32x4 pre_w2[6];
+  float pre_w1[8], pre_b1 = 0.f;
+  bool staged = false;
   for (int st = 0; st < n_steps; ++st) {
   // Everything lane-dependent is re-derived from an OPAQUE copy of the thread index inside the step loop: otherwise
   // hipcc hoists the step-invariant address arithmetic and MFMA operands of all phases out of the loop, keeps them
@@ -1432,14 +1440,22 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     u32x4* l_w2 = reinterpret_cast<u32x4*>(smem);                          // [npair][3][2][64]
     float* l_w1 = reinterpret_cast<float*>(l_w2 + npair * 6 * 64);         // [ntile][ns][64]
     float* l_b1 = l_w1 + ntile_l * p.lift_ns * 64;                         // [hid]
-    for (int i = tid; i < npair * 6 * 64; i += NT) l_w2[i] = p.lift_w2b[i];
-    for (int i = tid; i < ntile_l * p.lift_ns * 64; i += NT) l_w1[i] = p.lift_w1p[i];
-    for (int i = tid; i < p.lift_hid; i += NT) l_b1[i] = p.lift_b1[i];
+    if (!staged) {
+      for (int i = tid; i < npair * 6 * 64; i += NT) l_w2[i] = p.lift_w2b[i];
+      for (int i = tid; i < ntile_l * p.lift_ns * 64; i += NT) l_w1[i] = p.lift_w1p[i];
+      for (int i = tid; i < p.lift_hid; i += NT) l_b1[i] = p.lift_b1[i];
+    }
     f32x4 xs[4];
+    if (p.feed_regs && st > 0) {
+      xs[0] = vfeed;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float* cp = s < p.lift_ns ? chan_ptr(in, 4 * s + g, gs, (int)HW) : nullptr;
-      xs[s] = cp ? *reinterpret_cast<const f32x4*>(cp + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 1; s < 4; ++s) xs[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* cp = s < p.lift_ns ? chan_ptr(in, 4 * s + g, gs, (int)HW) : nullptr;
+        xs[s] = cp ? *reinterpret_cast<const f32x4*>(cp + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
     f32x4 bias2[2];
     bias2[0] = *reinterpret_cast<const f32x4*>(p.lift_b2 + 4 * g);
@@ -1911,7 +1927,8 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     if (g < p.cout) {
       const float b2 = p.proj_b2[g];
       v += f32x4{b2, b2, b2, b2};
-      if (resid_p) v += *reinterpret_cast<const f32x4*>(resid_p + (long long)gs * resid_bs + (long long)g * HW + pix);
+      if (p.feed_regs && st > 0) v += vfeed;      // the residual is the previous output: still in this lane's registers
+      else if (resid_p) v += *reinterpret_cast<const f32x4*>(resid_p + (long long)gs * resid_bs + (long long)g * HW + pix);
       if (*s_fail) v = f32x4{__uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u),
                              __uint_as_float(0x7fc00000u)};
       *reinterpret_cast<f32x4*>(out_p + (long long)gs * out_bs + (long long)g * HW + pix) = v;
@@ -1928,11 +1945,44 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     }
     if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
     if (st + 1 < n_steps) {
-      // the next step's input rows are the ones this wave has just written: drain the stores, drop any L1 copy,
-      // and let every wave finish with the projection weights before the lifting weights overwrite them
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      lds_barrier();
+      // the lifting weights of the next step: requested now, they travel while the slower waves finish the projection
+      const int npair_n = p.lift_hid >> 5, n_w2 = npair_n * 6 * 64, n_w1 = (p.lift_hid >> 4) * p.lift_ns * 64;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int i = tid + k * NT;
+        pre_w2[k] = p.lift_w2b[i < n_w2 ? i : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = tid + k * NT;
+        pre_w1[k] = p.lift_w1p[i < n_w1 ? i : 0];
+      }
+      pre_b1 = p.lift_b1[tid < p.lift_hid ? tid : 0];
+      if (p.feed_regs) {
+        vfeed = (g < p.cout) ? v : f32x4{0.f, 0.f, 0.f, 0.f};   // next input + residual: no store -> load round trip, no drain
+      } else {
+        // the next step's input rows are the ones this wave has just written: drain the stores, drop any L1 copy
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      lds_barrier();   // every wave is done with the projection weights: the lifting weights may overwrite them
+      {
+        u32x4* l_w2n = reinterpret_cast<u32x4*>(smem);
+        float* l_w1n = reinterpret_cast<float*>(l_w2n + n_w2);
+        float* l_b1n = l_w1n + n_w1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int i = tid + k * NT;
+          if (i < n_w2) l_w2n[i] = pre_w2[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = tid + k * NT;
+          if (i < n_w1) l_w1n[i] = pre_w1[k];
+        }
+        if (tid < p.lift_hid) l_b1n[tid] = pre_b1;
+      }
+      staged = true;
     }
     continue;
   }
@@ -2155,6 +2205,7 @@ using namespace dlwp::fno;
 // variables only as debug defaults read at that moment.  Nothing process-global selects a kernel after that.
 struct FnoKnobs {
   bool fp32_mfma = false;     // plain fp32-MFMA kernels + unfused spectral path (cross-check form)
+  bool feed_regs = true;      // persistent rollout: a step's input / residual stays in registers when it is the previous output (debug: DLWP_FNO_FEED_REGS=0)
   bool f16x3 = false;         // precision_form 2: the fused step kernel takes its big products as f16x3 (common.hpp)
   bool trunk = true;          // fused trunk kernel (DLWP_FNO_TRUNK=0 disables)
   int trunk_rows_forced = 0;  // DLWP_TRUNK_ROWS
@@ -2284,6 +2335,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
     FnoKnobs& k = p->k;
     // descriptor first; the environment only supplies debug defaults, read HERE and never again
     k.fp32_mfma = d->precision_form == 1 || env_int("DLWP_FP32_MFMA", 0) != 0;
+    k.feed_regs = env_int("DLWP_FNO_FEED_REGS", 1) != 0;
     k.f16x3 = !k.fp32_mfma && (d->precision_form == 2 || env_int("DLWP_FNO_F16X3", 0) != 0);
     k.trunk = env_int("DLWP_FNO_TRUNK", 1) != 0 && d->launch_form != 3;
     k.trunk_rows_forced = env_int("DLWP_TRUNK_ROWS", 0);
@@ -2689,6 +2741,8 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
         tp.r_const = io->constants; tp.r_presc = io->prescribed; tp.r_prog = io->prognostic; tp.r_out = io->rollout_out;
         tp.r_nconst = io->n_const; tp.r_npresc = io->n_presc; tp.r_nprog = io->n_prog; tp.r_T = io->T; tp.r_ctx = io->ctx;
         tp.r_t0 = io->t0;
+        tp.feed_regs = (io->n_const == 0 && io->n_presc == 0 && io->ctx == 1 && io->n_prog <= 4 && p->cin_steps == 1 &&
+                        p->cin == io->n_prog && p->k.feed_regs) ? 1 : 0;
       }
       const bool f16 = p->k.f16x3 && p->lift_w2h.p && p->proj_w1hp.p && !io->lift_only;
       if (f16) {   // f16x3 operands (the unfused kernels and the plain trunk keep bf16x6)
