@@ -121,7 +121,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // statement.  gfx950 needs two wait states between a packed-fp32 op and a dependent VALU op; with
 // fewer than three independent instructions in between hipcc pads with s_nop, each of which costs
 // a full issue slot on the (shared) fp32 pipe.  volatile keeps the hand interleave.
-__device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
+__device__ __forceinline__ void gelu_erf8_stmt(f32x4& u, f32x4& v) {
   const float x0 = u[0], x1 = u[1], x2 = u[2], x3 = u[3], x4 = v[0], x5 = v[1], x6 = v[2], x7 = v[3];
   float t0, t1, t2, t3, t4, t5, t6, t7;
   // The clamp constant sits in an SGPR the compiler cannot see through: with a literal it emits v_max |x|,|x| + v_min
@@ -179,6 +179,81 @@ __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
 #undef DLWP_F
   u = f32x4{r0, r1, r2, r3};
   v = f32x4{r4, r5, r6, r7};
+}
+
+// gelu_erf8 (the form every kernel uses; gelu_erf8_stmt above is the statement-per-instruction form it replaced, kept for A/B:
+// 1.515 -> 1.467 ms per FNO rollout): the whole polynomial in ONE asm block, exponentials / final combination in two more.  hipcc
+// pads every inline-asm statement it cannot see into (an s_nop per group of four packed FMAs, ~8 issue slots per call)
+// and reloads the seven coefficient pairs of the statement-per-instruction form from spilled SGPRs (v_readlane) when the
+// surrounding kernel is short of them.  Here the seven constants ride in three SGPR pairs (op_sel picks the half; the
+// final -1 is an inline constant), a dependent packed FMA has four other instructions behind its producer by construction
+// (three sibling chains + one max(x, 0)), and v_exp -> v_fma pairs are eight instructions apart.
+__device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
+  const float x0 = u[0], x1 = u[1], x2 = u[2], x3 = u[3], x4 = v[0], x5 = v[1], x6 = v[2], x7 = v[3];
+  float umax = DLWP_GELU_UMAX;
+  asm volatile("" : "+s"(umax));
+  // first reads of the inputs in plain C (MFMA -> VALU wait states are hipcc's to insert, see gelu_erf8)
+#define DLWP_CLAMP(x) __builtin_amdgcn_fmed3f(__builtin_fabsf(x), 0.f, umax)
+  const f32x2 ta = {DLWP_CLAMP(x0), DLWP_CLAMP(x1)}, tb = {DLWP_CLAMP(x2), DLWP_CLAMP(x3)};
+  const f32x2 tc = {DLWP_CLAMP(x4), DLWP_CLAMP(x5)}, td = {DLWP_CLAMP(x6), DLWP_CLAMP(x7)};
+#undef DLWP_CLAMP
+#define DLWP_CX(c) c,
+  constexpr float kc[6] = {DLWP_GELU_COEFFS(DLWP_CX) 0.f};
+#undef DLWP_CX
+  const f32x2 c01 = {DLWP_GELU_QTOP, kc[0]}, c23 = {kc[1], kc[2]}, c45 = {kc[3], kc[4]};
+  f32x2 pa, pb, pc, pd;
+  float m0, m1, m2, m3, m4, m5, m6, m7;
+  asm volatile(
+      "v_pk_fma_f32 %0, %20, %12, %20 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %20, %13, %20 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %2, %20, %14, %20 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %3, %20, %15, %20 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_max_f32_e32 %4, 0, %16\n\t"
+      "v_pk_fma_f32 %0, %0, %12, %21 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %13, %21 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %2, %2, %14, %21 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %3, %3, %15, %21 op_sel_hi:[1,1,0]\n\t"
+      "v_max_f32_e32 %5, 0, %17\n\t"
+      "v_pk_fma_f32 %0, %0, %12, %21 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %1, %1, %13, %21 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %2, %2, %14, %21 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %3, %3, %15, %21 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_max_f32_e32 %6, 0, %18\n\t"
+      "v_pk_fma_f32 %0, %0, %12, %22 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %13, %22 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %2, %2, %14, %22 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %3, %3, %15, %22 op_sel_hi:[1,1,0]\n\t"
+      "v_max_f32_e32 %7, 0, %19\n\t"
+      "v_pk_fma_f32 %0, %0, %12, %22 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %1, %1, %13, %22 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %2, %2, %14, %22 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %3, %3, %15, %22 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_max_f32_e32 %8, 0, %23\n\t"
+      "v_pk_fma_f32 %0, %0, %12, -1.0 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %13, -1.0 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %2, %2, %14, -1.0 op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %3, %3, %15, -1.0 op_sel_hi:[1,1,0]\n\t"
+      "v_max_f32_e32 %9, 0, %24\n\t"
+      "v_max_f32_e32 %10, 0, %25\n\t"
+      "v_max_f32_e32 %11, 0, %26"
+      : "=&v"(pa), "=&v"(pb), "=&v"(pc), "=&v"(pd), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4), "=&v"(m5),
+        "=&v"(m6), "=&v"(m7)
+      : "v"(ta), "v"(tb), "v"(tc), "v"(td), "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(c01), "s"(c23), "s"(c45), "v"(x4),
+        "v"(x5), "v"(x6), "v"(x7));
+  // exponentials into fresh registers (tied in / out operands on halves of a 64-bit pair cost a v_mov each), four elements
+  // per block (30-operand limit of an asm statement)
+  float e0, e1, e2, e3, e4, e5, e6, e7;
+#define DLWP_TAIL4(ea, eb, ec, ed, aa, ab, ac, ad, ma, mb, mc, md, xa, xb, xc, xd)                                     \
+  asm volatile("v_exp_f32_e32 %0, %8\n\tv_exp_f32_e32 %1, %9\n\tv_exp_f32_e32 %2, %10\n\tv_exp_f32_e32 %3, %11\n\t"    \
+               "v_fma_f32 %4, -|%12|, %0, %4\n\tv_fma_f32 %5, -|%13|, %1, %5\n\t"                                   \
+               "v_fma_f32 %6, -|%14|, %2, %6\n\tv_fma_f32 %7, -|%15|, %3, %7"                                        \
+               : "=&v"(ea), "=&v"(eb), "=&v"(ec), "=&v"(ed), "+v"(ma), "+v"(mb), "+v"(mc), "+v"(md)                   \
+               : "v"(aa), "v"(ab), "v"(ac), "v"(ad), "v"(xa), "v"(xb), "v"(xc), "v"(xd))
+  DLWP_TAIL4(e0, e1, e2, e3, pa.x, pa.y, pb.x, pb.y, m0, m1, m2, m3, x0, x1, x2, x3);
+  DLWP_TAIL4(e4, e5, e6, e7, pc.x, pc.y, pd.x, pd.y, m4, m5, m6, m7, x4, x5, x6, x7);
+#undef DLWP_TAIL4
+  u = f32x4{m0, m1, m2, m3};
+  v = f32x4{m4, m5, m6, m7};
 }
 
 // The same GELU on eight plain v_fma_f32 chains.  For kernels whose SIMD also issues bf16 MFMAs (its own or the

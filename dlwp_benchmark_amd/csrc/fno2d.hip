@@ -1886,14 +1886,38 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   }
   if (STEP && p.proj_hid > 0) {
     // ---- projection (+ residual): weights staged over the transpose tiles, B operand straight from the registers
-    lds_barrier();
+    // the projection weights are requested BEFORE the barrier that frees their LDS (they travel while the slower waves
+    // finish their rows) and written behind it
     const int ntile_p = p.proj_hid >> 4;
+    const int n_q1 = ntile_p * 3 * 64, n_q2 = ntile_p * p.proj_co * 16;
+    u32x4 pq1[6];
+    float pq2[2], pqb;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = tid + k * NT;
+      pq1[k] = p.proj_w1b[i < n_q1 ? i : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * NT;
+      pq2[k] = p.proj_w2v[i < n_q2 ? i : 0];
+    }
+    pqb = p.proj_b1[tid < p.proj_hid ? tid : 0];
+    lds_barrier();
     u32x4* q_w1 = reinterpret_cast<u32x4*>(smem);                          // [ntile][3][64]
     float* q_b1 = reinterpret_cast<float*>(q_w1 + ntile_p * 3 * 64);       // [hid]
     float* q_w2 = q_b1 + p.proj_hid;                                       // [ntile][co][16]
-    for (int i = tid; i < ntile_p * 3 * 64; i += NT) q_w1[i] = p.proj_w1b[i];
-    for (int i = tid; i < p.proj_hid; i += NT) q_b1[i] = p.proj_b1[i];
-    for (int i = tid; i < ntile_p * p.proj_co * 16; i += NT) q_w2[i] = p.proj_w2v[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = tid + k * NT;
+      if (i < n_q1) q_w1[i] = pq1[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * NT;
+      if (i < n_q2) q_w2[i] = pq2[k];
+    }
+    if (tid < p.proj_hid) q_b1[tid] = pqb;
     u32x4 bx[4][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
