@@ -1130,6 +1130,11 @@ constexpr int kTrunkMaxLayers = 8;
 #define DLWP_TRUNK_DFT_BF16 0
 #endif
 constexpr bool kDftBf16 = DLWP_TRUNK_DFT_BF16 != 0;
+// f16x3 step kernel: the two W-direction DFTs of the row phase on the f16 matrix instructions too (data split on the fly,
+// twiddles pre-split).  The bf16x6 attempt above was a wash (six dependent products + 11-slot splits); f16x3 halves both.
+#ifndef DLWP_F16_DFT
+#define DLWP_F16_DFT 1
+#endif
 constexpr int kSyStride = 528;   // floats per Y row in LDS: 16 k' x 32 c + 16 (bank spread for the P1 B reads)
 
 struct TrunkParams {
@@ -1321,6 +1326,7 @@ __device__ __forceinline__ void rollout_step_io(const TrunkParams& p, int t, lon
 // the projection MLP (+ residual) consumes the last one; their staged weights time-share the transpose tiles' LDS.
 // Forward W-direction DFT of the wave's 32 x 64 tile in its transpose area, bf16x6: A = 8 consecutive pixels of a channel
 // row (two 16-byte LDS reads, split into three bf16 parts), B = the pre-split twiddles.
+template <bool F16 = false>
 __device__ __forceinline__ void fwd_dft_bf16x6(const float* s_tr, const u32x4* s_ttb, int lane, f32x4 (&yacc)[2]) {
   const int j = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -1337,12 +1343,18 @@ __device__ __forceinline__ void fwd_dft_bf16x6(const float* s_tr, const u32x4* s
       for (int i = 0; i < 4; ++i) {
         unsigned hh, mm, ll;
         const float v0 = i < 2 ? a0[2 * i] : a1[2 * i - 4], v1 = i < 2 ? a0[2 * i + 1] : a1[2 * i - 3];
-        split3_pair(v0, v1, hh, mm, ll);
+        split_pair_x<F16>(v0, v1, hh, mm, ll);
         xa[0][i] = hh;
         xa[1][i] = mm;
         xa[2][i] = ll;
       }
-      yacc[ct] = mfma_bf16x6(xa, tb, yacc[ct]);
+      if constexpr (F16) {   // data on the A side: (xs, tm') (xm, th) (xh, th)
+        yacc[ct] = mfma16x16x32_f16(xa[1], tb[1], yacc[ct]);
+        yacc[ct] = mfma16x16x32_f16(xa[2], tb[0], yacc[ct]);
+        yacc[ct] = mfma16x16x32_f16(xa[0], tb[0], yacc[ct]);
+      } else {
+        yacc[ct] = mfma_bf16x6(xa, tb, yacc[ct]);
+      }
     }
   }
 }
@@ -1351,6 +1363,8 @@ template <int ROWS, int G, bool LL, bool STEP = false, bool F16 = false>
 __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkParams p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int W = 64, KP = 16, C = kC, NT = 64 * ROWS;
+  constexpr bool kDftF16 = F16 && (DLWP_F16_DFT != 0);
+  constexpr bool kDftMx = kDftBf16 || kDftF16;            // W-direction DFTs on the bf16 / f16 matrix instructions
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   float* s_tr = smem + wave * (C * kTrStride);            // [8][32][68]   per-wave transpose tile
@@ -1478,8 +1492,8 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         *reinterpret_cast<f32x4*>(s_tr + (16 * ot + 4 * g + r) * kTrStride + 4 * j) = vv[ot][r];
     wave_lds_fence();
     f32x4 yacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if constexpr (kDftBf16) {
-      fwd_dft_bf16x6(s_tr, s_ttb, lane, yacc);
+    if constexpr (kDftMx) {
+      fwd_dft_bf16x6<kDftF16>(s_tr, s_ttb, lane, yacc);
     } else {
 #pragma unroll
       for (int s = 0; s < 16; ++s)
@@ -1781,7 +1795,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         for (int r4 = 0; r4 < 4; ++r4)
           if (2 * g + (r4 >> 1) < ROWS) {
             const int kq = 2 * ky + (r4 & 1), o = 16 * nt + j;   // bf16 form keeps Z as [row][o][k'], fp32 form as [row][k'][o]
-            s_z[(2 * g + (r4 >> 1)) * (KP * C) + (kDftBf16 ? o * KP + kq : kq * C + o)] = d[r4] * ckw;
+            s_z[(2 * g + (r4 >> 1)) * (KP * C) + (kDftMx ? o * KP + kq : kq * C + o)] = d[r4] * ckw;
           }
       }
       wave_lds_fence();   // the transpose tile is reused for the next ky
@@ -1789,7 +1803,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     lds_barrier();
     DLWP_STAMP();
     // ---- the row itself
-    if constexpr (kDftBf16) {
+    if constexpr (kDftMx) {
       // inverse W-DFT, bf16x6: A = Z[o = 16 ot + j][k' = 8g .. 8g+7] (lane groups 2, 3 carry zeros: K = 16 of 32)
       u32x4 za[2][3];
 #pragma unroll
@@ -1804,7 +1818,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         for (int i = 0; i < 4; ++i) {
           unsigned hh, mm, ll;
           const float v0 = i < 2 ? z0[2 * i] : z1[2 * i - 4], v1 = i < 2 ? z0[2 * i + 1] : z1[2 * i - 3];
-          split3_pair(v0, v1, hh, mm, ll);
+          split_pair_x<kDftF16>(v0, v1, hh, mm, ll);
           za[ot][0][i] = hh;
           za[ot][1][i] = mm;
           za[ot][2][i] = ll;
@@ -1816,7 +1830,15 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp) tb[pp] = s_tb[(q * 3 + pp) * 64 + lane];
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) acc[ot][q] = mfma_bf16x6(za[ot], tb, acc[ot][q]);
+        for (int ot = 0; ot < 2; ++ot) {
+          if constexpr (kDftF16) {   // data on the A side: (zs, tm') (zm, th) (zh, th)
+            acc[ot][q] = mfma16x16x32_f16(za[ot][1], tb[1], acc[ot][q]);
+            acc[ot][q] = mfma16x16x32_f16(za[ot][2], tb[0], acc[ot][q]);
+            acc[ot][q] = mfma16x16x32_f16(za[ot][0], tb[0], acc[ot][q]);
+          } else {
+            acc[ot][q] = mfma_bf16x6(za[ot], tb, acc[ot][q]);
+          }
+        }
       }
     } else {
       float z[KP / 4][2];
@@ -1854,8 +1876,8 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
       wave_lds_fence();
       DLWP_STAMP();
       f32x4 yacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      if constexpr (kDftBf16) {
-        fwd_dft_bf16x6(s_tr, s_ttb, lane, yacc);
+      if constexpr (kDftMx) {
+        fwd_dft_bf16x6<kDftF16>(s_tr, s_ttb, lane, yacc);
       } else {
 #pragma unroll
         for (int s = 0; s < 16; ++s)
@@ -2042,6 +2064,7 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
   float fwd_scale = 1.f;
   DevBuf t, tt, ef, ei, ck;
   DevBuf tb, ttb;   // bf16x3 B operands of the W-direction DFTs for the fused kernel (W == 64, KP == 16 only)
+  DevBuf tbh, ttbh; // the same twiddles as f16x3 parts (th, tm' = (t - th) * 2^11, 0) for the f16x3 step kernel
 
   int32_t build(int H_, int W_, int M1_, int M2_, const int32_t* rows_in, const int32_t* rows_out,
                 float fwd, float inv, hipStream_t s) {
@@ -2079,6 +2102,7 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
       // inverse: B[k = k' = 8g + jj][col j -> pixel 4j + q]  -> [q][part][lane][dword]   (lanes g >= 2 supply zeros)
       // forward: B[k = pixel 32kb + 8g + jj][col j -> k' = j] -> [kb][part][lane][dword]
       std::vector<uint32_t> htb((size_t)4 * 3 * 64 * 4, 0u), httb((size_t)2 * 3 * 64 * 4, 0u);
+      std::vector<uint32_t> htbh(htb.size(), 0u), httbh(httb.size(), 0u);
       for (int l = 0; l < 64; ++l) {
         const int jj0 = l & 15, gg = l >> 4;
         for (int d = 0; d < 4; ++d) {
@@ -2087,6 +2111,15 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
             for (int e = 0; e < 2; ++e) {
               const int kp = 8 * gg + 2 * d + e;
               split3_host(kp < KP ? ht[(size_t)kp * W + 4 * jj0 + q] : 0.f, hh[e], mm[e], ll[e]);
+            }
+            {
+              uint16_t fh[2], fm[2];
+              for (int e = 0; e < 2; ++e) {
+                const int kp = 8 * gg + 2 * d + e;
+                split2_host_f16(kp < KP ? ht[(size_t)kp * W + 4 * jj0 + q] : 0.f, fh[e], fm[e]);
+              }
+              htbh[(((size_t)q * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)fh[0] | ((uint32_t)fh[1] << 16);
+              htbh[(((size_t)q * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)fm[0] | ((uint32_t)fm[1] << 16);
             }
             htb[(((size_t)q * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
             htb[(((size_t)q * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16);
@@ -2098,6 +2131,15 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
               const int w = 32 * kb + 8 * gg + 2 * d + e;
               split3_host(htt[(size_t)w * KP + jj0], hh[e], mm[e], ll[e]);
             }
+            {
+              uint16_t fh[2], fm[2];
+              for (int e = 0; e < 2; ++e) {
+                const int w = 32 * kb + 8 * gg + 2 * d + e;
+                split2_host_f16(htt[(size_t)w * KP + jj0], fh[e], fm[e]);
+              }
+              httbh[(((size_t)kb * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)fh[0] | ((uint32_t)fh[1] << 16);
+              httbh[(((size_t)kb * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)fm[0] | ((uint32_t)fm[1] << 16);
+            }
             httb[(((size_t)kb * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
             httb[(((size_t)kb * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16);
             httb[(((size_t)kb * 3 + 2) * 64 + l) * 4 + d] = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
@@ -2106,6 +2148,8 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
       }
       DLWP_HIP_CHECK(tb.upload(htb.data(), htb.size() * 4, s));
       DLWP_HIP_CHECK(ttb.upload(httb.data(), httb.size() * 4, s));
+      DLWP_HIP_CHECK(tbh.upload(htbh.data(), htbh.size() * 4, s));
+      DLWP_HIP_CHECK(ttbh.upload(httbh.data(), httbh.size() * 4, s));
       DLWP_HIP_CHECK(hipStreamSynchronize(s));
     }
     DLWP_HIP_CHECK(t.upload(ht.data(), ht.size() * 4, s));
@@ -2772,6 +2816,7 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
       if (f16) {   // f16x3 operands (the unfused kernels and the plain trunk keep bf16x6)
         tp.lift_w2b = p->lift_w2h.as<u32x4>();
         tp.proj_w1b = p->proj_w1hp.as<u32x4>();
+        tp.tb = p->sc.tbh.as<u32x4>(); tp.ttb = p->sc.ttbh.as<u32x4>();
         for (int l = 0; l < kTrunkMaxLayers; ++l) tp.wsb[l] = p->wshp[l < p->L ? l : 0].as<u32x4>();
       }
       if (G == 4) le = step_launch_one<4>(tp, s, f16);
