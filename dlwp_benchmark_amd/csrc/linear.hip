@@ -69,7 +69,9 @@ template <int BN, int NP, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   constexpr int TN = BN / 32;                        // 16-row W tiles per wave (wave tile: 64 m x BN/2 n)
   constexpr int NPW = F16 ? 2 : NP;                  // W parts staged per k-step
-  constexpr int XBYTES = NP * 8192;                  // x tile: NP parts x 128 rows x 64 bytes
+  constexpr int NPX = F16 ? 2 : NP;                  // x images in LDS (f16x3: xh and xm; xs = xh * 2^-11 is formed in registers --
+                                                     // the kernel is bound by LDS read bandwidth, ~430 bytes per matrix instruction)
+  constexpr int XBYTES = NPX * 8192;                 // x tile: NPX parts x 128 rows x 64 bytes
   constexpr int WPART = BN * 64, WSTAGE = NPW * WPART;
   constexpr int CH = NPW * BN * 4;                   // 16-byte chunks per W stage
   constexpr int PIECES = CH / 64;                    // 1 KiB LDS-DMA pieces (16 rows x 64 bytes) per W stage
@@ -165,8 +167,12 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
         split_pair_x<F16>(src[q][0], src[q][1], h0, m0_, l0);
         split_pair_x<F16>(src[q][2], src[q][3], h1, m1, l1);
         *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
-        *reinterpret_cast<uint2*>(d + 8192) = uint2{m0_, m1};
-        *reinterpret_cast<uint2*>(d + 16384) = uint2{l0, l1};
+        if constexpr (F16) {   // split order (xh, xs, xm): xm is the second image, xs is not stored
+          *reinterpret_cast<uint2*>(d + 8192) = uint2{l0, l1};
+        } else {
+          *reinterpret_cast<uint2*>(d + 8192) = uint2{m0_, m1};
+          *reinterpret_cast<uint2*>(d + 16384) = uint2{l0, l1};
+        }
       } else {
         *reinterpret_cast<uint2*>(d) = uint2{cvt_pk_bf16(src[q][0], src[q][1]), cvt_pk_bf16(src[q][2], src[q][3])};
       }
@@ -264,9 +270,15 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
     w_dma(cur ^ 1, cw);
     u32x4 xb[4][NP];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+      if constexpr (F16) {
+        xb[a][0] = *reinterpret_cast<const u32x4*>(xfrag + a * 1024);
+        xb[a][2] = *reinterpret_cast<const u32x4*>(xfrag + 8192 + a * 1024);
+      } else {
 #pragma unroll
-      for (int part = 0; part < NP; ++part) xb[a][part] = *reinterpret_cast<const u32x4*>(xfrag + part * 8192 + a * 1024);
+        for (int part = 0; part < NP; ++part) xb[a][part] = *reinterpret_cast<const u32x4*>(xfrag + part * 8192 + a * 1024);
+      }
+    }
     const unsigned char* wf = wfrag + cur * WSTAGE;
     u32x4 wa[NPW];         // the first W fragments too: the MFMAs can start right behind the barrier
 #pragma unroll
@@ -276,6 +288,12 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
     asm volatile("" ::: "memory");
     // x(t+1) has landed when at most this step's G loads of W are outstanding
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]), "+v"(px[3]) : "n"(G));
+    if constexpr (F16) {                     // xs = xh * 2^-11 (exact unless |x| < 0.125): 16 packed multiplies instead of 4 KB of LDS reads
+      const _Float16 k1 = (_Float16)0.00048828125f;
+      const f16x8 k = {k1, k1, k1, k1, k1, k1, k1, k1};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xb[a][1] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, xb[a][0]) * k);
+    }
     x_store(px);
     if (advance(cx)) x_rows(cx);
     x_issue(px, cx);                         // x(t+2), into the registers just split
@@ -352,7 +370,7 @@ static int32_t launch_v2(const Params& p, hipStream_t s) {
   // resident workgroups (2 per CU by LDS) of the CURRENT device, found once per device: hipFuncSetAttribute is per device too.
   // (atomic: concurrent first calls race benignly to the same value)
   static std::atomic<int> slots_of[64];
-  constexpr size_t lds = (size_t)NP * 8192 + 2 * (size_t)(F16 ? 2 : NP) * BN * 64;
+  constexpr size_t lds = (size_t)(F16 ? 2 : NP) * 8192 + 2 * (size_t)(F16 ? 2 : NP) * BN * 64;
   auto kern = linear_kernel<BN, NP, F16>;
   int dev = 0;
   DLWP_HIP_CHECK(hipGetDevice(&dev));
