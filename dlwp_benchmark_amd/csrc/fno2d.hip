@@ -290,8 +290,22 @@ __global__ __launch_bounds__(256) void pw_mlp2_kernel(const MlpParams p) {
 template <int CIN_STEPS, bool F16 = false>
 __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const float* s_w1, const float* s_b1,
                                              const u32x4* s_w2, int npair, int lane, const f32x4 (&bias2)[2],
-                                             f32x4 (&acc2)[2][4], int ns = CIN_STEPS) {
+                                             f32x4 (&acc2)[2][4], int ns = CIN_STEPS, bool cin1 = false) {
   const int g = lane >> 4;
+  // cin1 (ONE input channel, uniform): layer 1 is w1[c] * x + b1[c] -- 16 plain FMAs per unit instead of four fp32 matrix
+  // instructions that would multiply three zero k-slots each (the fp32 MFMA holds the vector lanes for 32 cycles).  Bit-identical:
+  // the matrix instruction is the same FMA chain with exact zeros added.  The channel's pixels sit in lane group g = 0;
+  // the other groups hold zeros, so two xor-shuffles + adds broadcast them exactly.
+  f32x4 xbc = {0.f, 0.f, 0.f, 0.f};
+  if (cin1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = xs[0][q];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      xbc[q] = v;
+    }
+  }
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -313,6 +327,14 @@ __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const
     for (int tt = 0; tt < 2; ++tt) {
       const int t = 2 * u + tt;
       const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 16 * t + 4 * g);
+      if (cin1) {   // s_w1 [tile][ns = 1][64]: lanes 0..15 of a tile hold w1[16 t + lane][0]
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(s_w1 + t * 64 + 4 * g);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a1[tt][qq][r] = __builtin_fmaf(wv[r], xbc[2 * qp + qq], bb[r]);
+        continue;
+      }
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) a1[tt][qq] = bb;
 #pragma unroll
@@ -1165,6 +1187,7 @@ struct TrunkParams {
   // STEP variant (lifting and projection inside the same launch):
   ChanTable in;            // the step's input channels (folds _prepare_inputs)
   int lift_ns, lift_hid;   // populated 4-deep k-steps of the input (<= 4), lifting width (<= 256, multiple of 32)
+  int lift_cin1;           // exactly one input channel: lifting layer 1 as plain FMAs (lift_segment)
   const float* lift_w1p;   // [hid/16][ns][64]
   const float* lift_b1;    // [hid]
   const u32x4* lift_w2b;   // [hid/32][3][2][64]
@@ -1477,7 +1500,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     lds_barrier();
     if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
     f32x4 acc2[2][4];
-    lift_segment<4, F16>(xs, l_w1, l_b1, l_w2, npair, lane, bias2, acc2, p.lift_ns);
+    lift_segment<4, F16>(xs, l_w1, l_b1, l_w2, npair, lane, bias2, acc2, p.lift_ns, p.lift_cin1 != 0);
     if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -2796,7 +2819,10 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
     hipError_t le = hipErrorInvalidValue;
     if (io) {
       tp.in = *io->in;
-      tp.lift_ns = p->cin_steps; tp.lift_hid = p->hid_l;
+      tp.lift_ns = p->cin_steps; tp.lift_hid = p->hid_l; tp.lift_cin1 = p->cin == 1 ? 1 : 0;
+#ifdef DLWP_NO_CIN1
+      tp.lift_cin1 = 0;   // A/B switch (tools/ab_build.sh)
+#endif
       tp.lift_w1p = p->lift_w1p.as<float>(); tp.lift_b1 = p->lift_b1.as<float>();
       tp.lift_w2b = p->lift_w2b.as<u32x4>(); tp.lift_b2 = p->lift_b2.as<float>();
       tp.proj_hid = p->hid_p; tp.proj_co = p->proj_co; tp.cout = p->cout;
