@@ -1157,6 +1157,9 @@ constexpr bool kDftBf16 = DLWP_TRUNK_DFT_BF16 != 0;
 #ifndef DLWP_F16_DFT
 #define DLWP_F16_DFT 1
 #endif
+#ifndef DLWP_PREFETCH_EARLY
+#define DLWP_PREFETCH_EARLY 0   // measured: 1 (the next step's lifting weights requested BEFORE the projection) spills 38 registers
+#endif                          // per lane and loses 8 % (1.501 vs 1.385 ms per rollout); 0 = right before the end-of-step barrier
 constexpr int kSyStride = 528;   // floats per Y row in LDS: 16 k' x 32 c + 16 (bank spread for the P1 B reads)
 
 struct TrunkParams {
@@ -1975,6 +1978,25 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         bx[q][2][i] = ll;
       }
     lds_barrier();
+    // the lifting weights of the next step, requested into registers: DLWP_PREFETCH_EARLY = 1 before the projection (they
+    // travel under its 16 us), 0 right before the end-of-step barrier (~2 us of L2 latency stay exposed behind it)
+    auto lift_prefetch = [&]() {
+      const int n_w2p = (p.lift_hid >> 5) * 6 * 64, n_w1p = (p.lift_hid >> 4) * p.lift_ns * 64;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int i = tid + k * NT;
+        pre_w2[k] = p.lift_w2b[i < n_w2p ? i : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = tid + k * NT;
+        pre_w1[k] = p.lift_w1p[i < n_w1p ? i : 0];
+      }
+      pre_b1 = p.lift_b1[tid < p.lift_hid ? tid : 0];
+    };
+#if DLWP_PREFETCH_EARLY
+    if (st + 1 < n_steps) lift_prefetch();
+#endif
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     auto run = [&](auto coc) {
       constexpr int CO = decltype(coc)::value;
@@ -2014,19 +2036,10 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     }
     if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
     if (st + 1 < n_steps) {
-      // the lifting weights of the next step: requested now, they travel while the slower waves finish the projection
       const int npair_n = p.lift_hid >> 5, n_w2 = npair_n * 6 * 64, n_w1 = (p.lift_hid >> 4) * p.lift_ns * 64;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int i = tid + k * NT;
-        pre_w2[k] = p.lift_w2b[i < n_w2 ? i : 0];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = tid + k * NT;
-        pre_w1[k] = p.lift_w1p[i < n_w1 ? i : 0];
-      }
-      pre_b1 = p.lift_b1[tid < p.lift_hid ? tid : 0];
+#if !DLWP_PREFETCH_EARLY
+      lift_prefetch();
+#endif
       if (p.feed_regs) {
         vfeed = (g < p.cout) ? v : f32x4{0.f, 0.f, 0.f, 0.f};   // next input + residual: no store -> load round trip, no drain
       } else {
