@@ -167,7 +167,8 @@ def _attn_tag(name, a):
         d = a[0]._obj
         return (tuple(d.padded), tuple(d.window), int(d.heads), int(d.head_dim), int(a[5]), int(d.use_mask))   # a[5] = batch
     if name.startswith("dlwp_linear_") and "pack" not in name:
-        return (int(a[5]), int(a[6]), int(a[7]), int(a[8]), a[3] is not None)      # rows, in, out, act, residual operand
+        io = (int(a[9]), int(a[10])) if name.endswith("_io") else (0, 0)         # bf16 tensor on the x / out side
+        return (int(a[5]), int(a[6]), int(a[7]), int(a[8]), a[3] is not None) + io  # rows, in, out, act, residual operand
     return None
 
 
@@ -232,7 +233,8 @@ def bench_other_configs(device, only=None, reps=2):
             what = {"fp32": "fp32", "bf16": "bf16 window attention (fp32 elsewhere)",
                     "f16x3": "fp32 (block-tail MLP products from exact two-part f16 splits, dlwp_afno_block_tail_f16x3)" if cls == "FourCastNet"
                              else "fp32 (Linear products from exact two-part f16 splits, dlwp_linear_f16x3; fp32-accurate attention)",
-                    "bf16all": "bf16 window attention and bf16 Linear operands (fp32 accumulation, LayerNorm, residual stream)"}[variant]
+                    "bf16all": "bf16 window attention and bf16 Linear operands (fp32 accumulation, LayerNorm, residual stream; the MLP's hidden "
+                               "activation crosses HBM as bf16)"}[variant]
             entry = {"workload": f"{cls} {h}x{w}, {cfg['prognostic_channels']} prognostic ch, {steps}-step rollout, {what}",
                      "batch": batch, "rollout_steps": steps, "weights": "deterministic filler sha256:" + sha[:16],
                      "launch": "one_step replayed as a HIP graph (set_step_graphs)" if graphs_on else "eager launches"}
@@ -288,17 +290,18 @@ def _linear_roofline(summ):
     """the Linear kernel's costliest shape class: algorithmic flops 2 M K N (bias / GELU / residual not counted) / event time,
     priced against the fp32 matrix peak for dlwp_linear_f32 (fp32-accurate: six bf16 products per fp32 one are not credited)
     and against the dense bf16 peak for dlwp_linear_bf16."""
-    lin = {k: v for k, v in summ.items() if k[0] in ("dlwp_linear_f32", "dlwp_linear_bf16", "dlwp_linear_f16x3")}
+    lin = {k: v for k, v in summ.items() if k[0] in ("dlwp_linear_f32", "dlwp_linear_bf16", "dlwp_linear_f16x3", "dlwp_linear_bf16_io")}
     if not lin:
         return None
     (name, tag), v = max(lin.items(), key=lambda kv: kv[1]["total_ms"])
-    rows, k, n, act, resid = tag
+    rows, k, n, act, resid, xb, ob = tag
     fl = 2.0 * rows * k * n
-    by = 4.0 * rows * (k + n * (2 if resid else 1))
-    peak = MFMA_BF16_PEAK_TF if name.endswith("bf16") else MFMA_F32_PEAK_TF
+    by = rows * ((2.0 if xb else 4.0) * k + (2.0 if ob else 4.0) * n + (4.0 * n if resid else 0.0))
+    peak = MFMA_BF16_PEAK_TF if "bf16" in name else MFMA_F32_PEAK_TF
     ach = fl / (v["avg_ms"] * 1e-3) / 1e12
     tot = sum(x["total_ms"] for x in lin.values())
-    return {"kernel": f"linear_kernel via {name} ({rows} x {k} -> {n}{', GELU' if act else ''}{', + residual' if resid else ''})",
+    return {"kernel": f"linear_kernel via {name} ({rows} x {k} -> {n}{', GELU' if act else ''}{', + residual' if resid else ''}"
+                      f"{', bf16 input' if xb else ''}{', bf16 output' if ob else ''})",
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
             "hbm_view_GBps": by / (v["avg_ms"] * 1e-3) / 1e9, "avg_launch_ms": v["avg_ms"], "launches_per_rollout": v["calls"],

@@ -57,6 +57,10 @@ __device__ __forceinline__ void store4(float* dst, const f32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 }
 
+__device__ __forceinline__ void store2(unsigned short* dst, const uint2& v) {
+  asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ int swz(int row) { return (4 - ((row & 15) >> 2)) & 3; }
 
 struct Cursor {          // one (tile, k-step) position of this workgroup's flattened step sequence
@@ -65,8 +69,13 @@ struct Cursor {          // one (tile, k-step) position of this workgroup's flat
 
 // F16 (dlwp_linear_f16x3, NP = 3): the "f16x3" form of common.hpp -- x parts (xh, xh * 2^-11, xm), W parts (wh, wm' = (w - wh) * 2^11),
 // three f16 products per output instead of six bf16 ones, 5 instead of 11 split slots per pair; only TWO W images are staged.
-template <int BN, int NP, bool F16 = false>
+// XB16 / OB16 (bf16-operand form only): x is ALREADY bf16 [M][K] / the output is stored as bf16 [M][N].  The MLP of a block
+// in the bf16 form hands its hidden activation from fc1 to fc2 this way: fc2 rounds its input to bf16 anyway, so the
+// result is bit-identical and the widest tensor of the block crosses HBM at half the bytes in both directions.
+template <int BN, int NP, bool F16 = false, bool XB16 = false, bool OB16 = false>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
+  static_assert(!(XB16 || OB16) || (NP == 1 && !F16), "bf16 in / out exists for the bf16-operand form");
+  constexpr int XQ = XB16 ? 2 : 4;                   // 16-byte x loads per thread and k-step
   constexpr int TN = BN / 32;                        // 16-row W tiles per wave (wave tile: 64 m x BN/2 n)
   constexpr int NPW = F16 ? 2 : NP;                  // W parts staged per k-step
   constexpr int NPX = F16 ? 2 : NP;                  // x images in LDS (f16x3: xh and xm; xs = xh * 2^-11 is formed in registers --
@@ -112,17 +121,24 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   unsigned xoff[4];
   auto x_rows = [&](const Cursor& c) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = tid + q * 256, r = i >> 3, c4 = i & 7;
+    for (int q = 0; q < XQ; ++q) {
       const long long left = p.M - 1 - row0(c);                   // rows past M: clamped to the last row, never stored
-      const int rr = r < left ? r : (int)left;
-      xoff[q] = ((unsigned)rr * (unsigned)p.K + 4u * c4) * 4u;
+      if constexpr (XB16) {                                       // a row of the k-step is 64 bytes = four 16-byte chunks of 8 bf16
+        const int i = tid + q * 256, r = i >> 2, c8 = i & 3;
+        const int rr = r < left ? r : (int)left;
+        xoff[q] = ((unsigned)rr * (unsigned)p.K + 8u * c8) * 2u;
+      } else {
+        const int i = tid + q * 256, r = i >> 3, c4 = i & 7;
+        const int rr = r < left ? r : (int)left;
+        xoff[q] = ((unsigned)rr * (unsigned)p.K + 4u * c4) * 4u;
+      }
     }
   };
   auto x_issue = [&](f32x4 (&dst)[4], const Cursor& c) {
-    const float* base = p.x + row0(c) * p.K + c.ks * BK;
+    const float* base = XB16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p.x) + row0(c) * p.K + c.ks * BK)
+                             : p.x + row0(c) * p.K + c.ks * BK;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[q]) : "v"(xoff[q]), "s"(base));
+    for (int q = 0; q < XQ; ++q) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[q]) : "v"(xoff[q]), "s"(base));
   };
   // ---- W stream: NP x BN rows x 64 bytes per k-step = PIECES 1 KiB pieces (16 rows x 64 bytes) moved global -> LDS by
   // global_load_lds_dwordx4: no registers, no ds_write.  Wave w moves pieces w, w + 4, ... (a wave whose last index
@@ -158,6 +174,14 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   };
   // ---- split a register set into the x tile
   auto x_store = [&](const f32x4 (&src)[4]) {
+    if constexpr (XB16) {   // already bf16: a plain (swizzled) copy
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        const int i = tid + q * 256, r = i >> 2, c8 = i & 3;
+        *reinterpret_cast<f32x4*>(smem + r * 64 + ((c8 ^ swz(r)) << 4)) = src[q];
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = tid + q * 256, r = i >> 3, c4 = i & 7;
@@ -253,8 +277,14 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
         }
         const int n = nbase + 16 * b;
         if (n < p.N) {
-          if (m_u < p.M) store4(p.out + m_u * p.N + n, u);
-          if (m_v < p.M) store4(p.out + m_v * p.N + n, v);
+          if constexpr (OB16) {
+            unsigned short* ob = reinterpret_cast<unsigned short*>(p.out);
+            if (m_u < p.M) store2(ob + m_u * p.N + n, uint2{cvt_pk_bf16(u[0], u[1]), cvt_pk_bf16(u[2], u[3])});
+            if (m_v < p.M) store2(ob + m_v * p.N + n, uint2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])});
+          } else {
+            if (m_u < p.M) store4(p.out + m_u * p.N + n, u);
+            if (m_v < p.M) store4(p.out + m_v * p.N + n, v);
+          }
         }
       }
     }
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
       if (p.resid) epilogue(std::true_type{}); else epilogue(std::false_type{});
     }
     advance(cc);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // W(t+1) is in its buffer (queued behind it: x(t+2))
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XQ) : "memory");   // W(t+1) is in its buffer (queued behind it: the XQ loads of x(t+2))
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the x tile and W buffer writes are done
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -365,13 +395,13 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restric
 }
 
 
-template <int BN, int NP, bool F16 = false>
+template <int BN, int NP, bool F16 = false, bool XB16 = false, bool OB16 = false>
 static int32_t launch_v2(const Params& p, hipStream_t s) {
   // resident workgroups (2 per CU by LDS) of the CURRENT device, found once per device: hipFuncSetAttribute is per device too.
   // (atomic: concurrent first calls race benignly to the same value)
   static std::atomic<int> slots_of[64];
   constexpr size_t lds = (size_t)(F16 ? 2 : NP) * 8192 + 2 * (size_t)(F16 ? 2 : NP) * BN * 64;
-  auto kern = linear_kernel<BN, NP, F16>;
+  auto kern = linear_kernel<BN, NP, F16, XB16, OB16>;
   int dev = 0;
   DLWP_HIP_CHECK(hipGetDevice(&dev));
   DLWP_REQUIRE(dev >= 0 && dev < 64, DLWP_ERR_UNSUPPORTED, "linear: device ordinal %d", dev);
@@ -401,6 +431,8 @@ static int32_t launch(const Params& p, int form, hipStream_t s) {
   const bool narrow = (p.N % 128) != 0 && (p.N % 128) <= 96 && (p.N % 96 == 0 || p.N < 128);
   if (form == 3) return narrow ? launch_v2<96, 3>(p, s) : launch_v2<128, 3>(p, s);
   if (form == 2) return narrow ? launch_v2<96, 3, true>(p, s) : launch_v2<128, 3, true>(p, s);
+  if (form == 4) return narrow ? launch_v2<96, 1, false, true, false>(p, s) : launch_v2<128, 1, false, true, false>(p, s);   // bf16 x
+  if (form == 5) return narrow ? launch_v2<96, 1, false, false, true>(p, s) : launch_v2<128, 1, false, false, true>(p, s);   // bf16 out
   return narrow ? launch_v2<96, 1>(p, s) : launch_v2<128, 1>(p, s);
 }
 
@@ -487,4 +519,17 @@ extern "C" int32_t dlwp_linear_f16x3(const float* x_dev, const void* packed_dev,
                                      float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
                                      void* stream) {
   return linear_run(2, x_dev, packed_dev, bias_dev, resid_dev, out_dev, rows, in_features, out_features, act, stream);
+}
+
+// bf16-operand Linear with a bf16 tensor on one side (the hidden activation of a block's MLP in the bf16 form):
+//   x_is_bf16:   x_dev is bf16 [rows][in]  (what dlwp_linear_bf16 would round its fp32 input to -- bit-identical result);
+//   out_is_bf16: out_dev is bf16 [rows][out], rounded to nearest even after bias / GELU (no residual operand).
+// Exactly one of the two flags; everything else as dlwp_linear_bf16.
+extern "C" int32_t dlwp_linear_bf16_io(const void* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                                       void* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
+                                       int32_t x_is_bf16, int32_t out_is_bf16, void* stream) {
+  DLWP_REQUIRE((x_is_bf16 != 0) != (out_is_bf16 != 0), DLWP_ERR_INVALID_ARGUMENT, "linear_bf16_io: exactly one of x / out is bf16");
+  DLWP_REQUIRE(!(out_is_bf16 && resid_dev), DLWP_ERR_UNSUPPORTED, "linear_bf16_io: a bf16 output takes no residual operand");
+  return linear_run(x_is_bf16 ? 4 : 5, reinterpret_cast<const float*>(x_dev), packed_dev, bias_dev, resid_dev,
+                    reinterpret_cast<float*>(out_dev), rows, in_features, out_features, act, stream);
 }

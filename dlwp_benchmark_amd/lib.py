@@ -97,6 +97,8 @@ SIGNATURES = {
                                   c_void_p]),
     "dlwp_linear_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32,
                                    c_void_p]),
+    "dlwp_linear_bf16_io": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32,
+                                      c_int32, c_int32, c_void_p]),
     "dlwp_linear_pack_f16x3": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "dlwp_linear_f16x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32,
                                     c_void_p]),
@@ -212,7 +214,7 @@ class KernelTimer:
         import torch
 
         lib = load()
-        names = self.names or [n for n in SIGNATURES if n.endswith(("_f32", "_bf16", "_f16x3"))]
+        names = self.names or [n for n in SIGNATURES if n.endswith(("_f32", "_bf16", "_f16x3", "_bf16_io"))]
         for name in names:
             fn = getattr(lib, name)
             self._saved[name] = fn

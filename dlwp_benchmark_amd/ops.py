@@ -699,8 +699,10 @@ class LinearWeights:
 
 
 def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, precision: str = "fp32", out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """act(x @ m.weight.T + m.bias) + resid over the last dimension in one launch; act 0 none / 1 exact GELU.
+    precision "bf16" only: x may BE a bfloat16 tensor, or out_dtype=torch.bfloat16 asks for a bfloat16 result (no residual) --
+    dlwp_linear_bf16_io, the hand-over of an MLP's hidden activation at half the bytes, bit-identical to the fp32 hand-over.
     precision "fp32": dlwp_linear_f32, fp32-accurate GEMM on the bf16 matrix pipe (six products of exact three-way splits);
     "bf16": dlwp_linear_bf16, bf16 operands and fp32 accumulation (what autocast(bfloat16) makes of nn.Linear);
     "f16x3": dlwp_linear_f16x3, fp32-GEMM accuracy from exact two-part f16 splits (three products; |x| < 65504).
@@ -716,7 +718,15 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
         elif act != 0:
             raise _lib.DlwpError(f"linear: activation {act} not supported")
         return y if resid is None else y + resid
-    _lib.require_cuda_tensor(x, "x")
+    x_bf16 = x.dtype == torch.bfloat16
+    o_bf16 = out_dtype == torch.bfloat16 or (out is not None and out.dtype == torch.bfloat16)
+    if x_bf16 or o_bf16:
+        if precision != "bf16" or (x_bf16 and o_bf16) or (o_bf16 and resid is not None):
+            raise _lib.DlwpError("linear: a bfloat16 tensor is taken on ONE side, by precision='bf16', without a residual on a bfloat16 output")
+        if not x.is_cuda:
+            raise _lib.DlwpError("linear: x must be a CUDA tensor")
+    else:
+        _lib.require_cuda_tensor(x, "x")
     if act not in (0, 1):
         raise _lib.DlwpError(f"linear: activation {act} not supported")
     x = x.contiguous()
@@ -734,13 +744,19 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
         if tuple(resid.shape) != shape or not resid.is_contiguous():
             raise _lib.DlwpError("linear: resid must be contiguous and shaped like the output")
     if out is None:
-        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+        out = torch.empty(shape, device=x.device, dtype=torch.bfloat16 if o_bf16 else torch.float32)
     elif tuple(out.shape) != shape or not out.is_contiguous():
         raise _lib.DlwpError("linear: out must be contiguous and shaped like the output")
     if out.data_ptr() == x.data_ptr():
         raise _lib.DlwpError("linear: out must not alias x")
     lib = _lib.load()
     with torch.cuda.device(x.device):
+        if x_bf16 or o_bf16:
+            _lib.check(lib.dlwp_linear_bf16_io(x.data_ptr(), packed.data_ptr(),
+                                               m.bias.contiguous().data_ptr() if m.bias is not None else None,
+                                               resid.data_ptr() if resid is not None else None, out.data_ptr(), x.numel() // k,
+                                               k, n, int(act), int(x_bf16), int(o_bf16), _lib.stream_ptr()), "dlwp_linear_bf16_io")
+            return out
         name = {"fp32": "dlwp_linear_f32", "bf16": "dlwp_linear_bf16", "f16x3": "dlwp_linear_f16x3"}[precision]
         _lib.check(getattr(lib, name)(x.data_ptr(), packed.data_ptr(),
                                       m.bias.contiguous().data_ptr() if m.bias is not None else None,
@@ -835,7 +851,8 @@ def attention_block_tail(x: torch.Tensor, attn_out: torch.Tensor, proj: torch.nn
     epilogues) and one LayerNorm."""
     linear(attn_out, proj, resid=x, out=x, precision=precision)
     n2 = layer_norm(x, norm2.weight, norm2.bias, norm2.eps)
-    hid = linear(n2, fc1, act=1, precision=precision)
+    # bf16 form: the hidden activation crosses HBM as bfloat16 (fc2 rounds its input to bf16 anyway: bit-identical)
+    hid = linear(n2, fc1, act=1, precision=precision, out_dtype=torch.bfloat16 if precision == "bf16" else None)
     linear(hid, fc2, resid=x, out=x, precision=precision)
     return x
 

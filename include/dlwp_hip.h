@@ -336,6 +336,13 @@ int32_t dlwp_linear_bf16(const float* x_dev, const void* packed_dev, const float
  * contract; LayerNorm / GELU / attention outputs are orders of magnitude inside it) and for activations that are not
  * all tiny (the residual of |x| < 0.125 is an f16 subnormal, absolute spacing 2^-24).  `packed_dev` comes from
  * dlwp_linear_pack_f16x3 (same byte count as dlwp_linear_packed_bytes). */
+/* dlwp_linear_bf16 with a bf16 TENSOR on one side -- how the MLP of a block hands its hidden activation from fc1 to fc2 in the
+ * bf16 form (swin_transformer.py:21-39 under autocast): x_is_bf16: x_dev is bf16 [rows][in] (the values dlwp_linear_bf16 would round
+ * its fp32 input to: bit-identical result); out_is_bf16: out_dev is bf16 [rows][out], rounded to nearest even after bias / GELU,
+ * resid_dev must be NULL.  Exactly one of the two flags. */
+int32_t dlwp_linear_bf16_io(const void* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
+                            void* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
+                            int32_t x_is_bf16, int32_t out_is_bf16, void* stream);
 int32_t dlwp_linear_pack_f16x3(const float* weight_dev, int32_t out_features, int32_t in_features, void* packed_dev, void* stream);
 int32_t dlwp_linear_f16x3(const float* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
                           float* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act, void* stream);

@@ -268,3 +268,25 @@ def test_linear_random_shape_sweep():
                 want = want + r.double()
         assert torch.isfinite(got).all(), (trial, rows, k, n)
         assert rel_l2(got, want) <= 1e-6, (trial, rows, k, n, act, has_res, has_bias, prec, rel_l2(got, want))
+
+
+@pytest.mark.parametrize("rows,c,hid", [(4096, 96, 384), (1000, 192, 768), (2051, 384, 1536), (77, 96, 384)])
+def test_linear_bf16_hidden_handover_is_bit_identical(rows, c, hid):
+    """dlwp_linear_bf16_io: in the bf16 form the hidden activation of a block's MLP goes from fc1 to fc2 AS bfloat16 (half the
+    bytes both ways).  fc2 rounds its fp32 input to bf16 to nearest even -- the rounding fc1's epilogue now does -- so the
+    block output must be bit-identical to the fp32 hand-over; the bf16 tensor itself equals the rounded fp32 one."""
+    from dlwp_benchmark_amd import ops
+
+    fc1, fc2 = _linear(c, hid, True, seed=rows), _linear(hid, c, True, seed=rows + 1)
+    g = torch.Generator().manual_seed(rows + c)
+    x = torch.randn(rows, c, generator=g).to(DEV)
+    r = torch.randn(rows, c, generator=g).to(DEV)
+    with torch.no_grad():
+        h32 = ops.linear(x, fc1, act=1, precision="bf16")
+        h16 = ops.linear(x, fc1, act=1, precision="bf16", out_dtype=torch.bfloat16)
+        assert h16.dtype == torch.bfloat16 and torch.equal(h16, h32.bfloat16())
+        y32 = ops.linear(h32, fc2, resid=r, precision="bf16")
+        y16 = ops.linear(h16, fc2, resid=r, precision="bf16")
+    assert torch.equal(y16, y32)
+    with pytest.raises(Exception):
+        ops.linear(h16, fc2, precision="fp32")
