@@ -433,6 +433,7 @@ static int32_t launch(const Params& p, int form, hipStream_t s) {
   if (form == 2) return narrow ? launch_v2<96, 3, true>(p, s) : launch_v2<128, 3, true>(p, s);
   if (form == 4) return narrow ? launch_v2<96, 1, false, true, false>(p, s) : launch_v2<128, 1, false, true, false>(p, s);   // bf16 x
   if (form == 5) return narrow ? launch_v2<96, 1, false, false, true>(p, s) : launch_v2<128, 1, false, false, true>(p, s);   // bf16 out
+  if (form == 6) return narrow ? launch_v2<96, 1, false, true, true>(p, s) : launch_v2<128, 1, false, true, true>(p, s);     // both
   return narrow ? launch_v2<96, 1>(p, s) : launch_v2<128, 1>(p, s);
 }
 
@@ -524,12 +525,12 @@ extern "C" int32_t dlwp_linear_f16x3(const float* x_dev, const void* packed_dev,
 // bf16-operand Linear with a bf16 tensor on one side (the hidden activation of a block's MLP in the bf16 form):
 //   x_is_bf16:   x_dev is bf16 [rows][in]  (what dlwp_linear_bf16 would round its fp32 input to -- bit-identical result);
 //   out_is_bf16: out_dev is bf16 [rows][out], rounded to nearest even after bias / GELU (no residual operand).
-// Exactly one of the two flags; everything else as dlwp_linear_bf16.
+// At least one of the two flags; everything else as dlwp_linear_bf16.
 extern "C" int32_t dlwp_linear_bf16_io(const void* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
                                        void* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
                                        int32_t x_is_bf16, int32_t out_is_bf16, void* stream) {
-  DLWP_REQUIRE((x_is_bf16 != 0) != (out_is_bf16 != 0), DLWP_ERR_INVALID_ARGUMENT, "linear_bf16_io: exactly one of x / out is bf16");
+  DLWP_REQUIRE(x_is_bf16 || out_is_bf16, DLWP_ERR_INVALID_ARGUMENT, "linear_bf16_io: neither side is bf16 (that is dlwp_linear_bf16)");
   DLWP_REQUIRE(!(out_is_bf16 && resid_dev), DLWP_ERR_UNSUPPORTED, "linear_bf16_io: a bf16 output takes no residual operand");
-  return linear_run(x_is_bf16 ? 4 : 5, reinterpret_cast<const float*>(x_dev), packed_dev, bias_dev, resid_dev,
+  return linear_run(x_is_bf16 ? (out_is_bf16 ? 6 : 4) : 5, reinterpret_cast<const float*>(x_dev), packed_dev, bias_dev, resid_dev,
                     reinterpret_cast<float*>(out_dev), rows, in_features, out_features, act, stream);
 }

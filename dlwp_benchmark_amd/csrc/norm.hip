@@ -9,7 +9,8 @@
 namespace dlwp {
 namespace norm {
 
-template <int LPR, int NV>
+// OB16: y is bf16 [rows][C] (rounded to nearest even) -- for a consumer that rounds its input to bf16 anyway (dlwp_linear_bf16_io)
+template <int LPR, int NV, bool OB16 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pre,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
@@ -66,7 +67,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = fmaf((xv[v][k] - mean) * rstd, gm[v][k], bt[v][k]);
-        *reinterpret_cast<f32x4*>(y + row * C + 4 * iv) = o;
+        if constexpr (OB16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + row * C + 4 * iv) = uint2{cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3])};
+        else
+          *reinterpret_cast<f32x4*>(y + row * C + 4 * iv) = o;
       }
     }
   }
@@ -74,13 +78,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 template <int LPR, int NV>
 static int32_t launch(const float* x, const float* pre, const float* g, const float* b, float* y, long long rows, int C,
-                      float eps, hipStream_t s) {
+                      float eps, hipStream_t s, bool ob16 = false) {
   constexpr int RPW = 64 / LPR;
   long long waves = (rows + RPW - 1) / RPW;
   long long blocks = (waves + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((layernorm_kernel<LPR, NV>), dim3((unsigned)blocks), dim3(256), 0, s, x, pre, g, b, y, rows, C, eps);
+  if (ob16) hipLaunchKernelGGL((layernorm_kernel<LPR, NV, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, pre, g, b, y, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<LPR, NV>), dim3((unsigned)blocks), dim3(256), 0, s, x, pre, g, b, y, rows, C, eps);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
@@ -90,25 +95,36 @@ static int32_t launch(const float* x, const float* pre, const float* g, const fl
 
 using namespace dlwp;
 
-extern "C" int32_t dlwp_layernorm_prebias_f32(const float* x, const float* pre, const float* gamma, const float* beta,
-                                              float* y, int64_t rows, int32_t channels, float eps, void* stream) {
+static int32_t layernorm_prebias(const float* x, const float* pre, const float* gamma, const float* beta,
+                                 float* y, int64_t rows, int32_t channels, float eps, void* stream, bool ob16) {
   DLWP_REQUIRE(x && gamma && beta && y, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(rows > 0 && channels > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
   DLWP_REQUIRE(channels % 4 == 0 && channels <= 2048, DLWP_ERR_UNSUPPORTED,
                "channels %d: must be a multiple of 4 and <= 2048", channels);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nvec = channels / 4;
-  if (nvec <= 16) return norm::launch<16, 1>(x, pre, gamma, beta, y, rows, channels, eps, s);
-  if (nvec <= 32) return norm::launch<32, 1>(x, pre, gamma, beta, y, rows, channels, eps, s);
+  if (nvec <= 16) return norm::launch<16, 1>(x, pre, gamma, beta, y, rows, channels, eps, s, ob16);
+  if (nvec <= 32) return norm::launch<32, 1>(x, pre, gamma, beta, y, rows, channels, eps, s, ob16);
   const int nv = (nvec + 63) / 64;
   switch (nv) {
-    case 1: return norm::launch<64, 1>(x, pre, gamma, beta, y, rows, channels, eps, s);
-    case 2: return norm::launch<64, 2>(x, pre, gamma, beta, y, rows, channels, eps, s);
-    case 3: return norm::launch<64, 3>(x, pre, gamma, beta, y, rows, channels, eps, s);
-    case 4: return norm::launch<64, 4>(x, pre, gamma, beta, y, rows, channels, eps, s);
-    case 5: case 6: return norm::launch<64, 6>(x, pre, gamma, beta, y, rows, channels, eps, s);
-    default: return norm::launch<64, 8>(x, pre, gamma, beta, y, rows, channels, eps, s);
+    case 1: return norm::launch<64, 1>(x, pre, gamma, beta, y, rows, channels, eps, s, ob16);
+    case 2: return norm::launch<64, 2>(x, pre, gamma, beta, y, rows, channels, eps, s, ob16);
+    case 3: return norm::launch<64, 3>(x, pre, gamma, beta, y, rows, channels, eps, s, ob16);
+    case 4: return norm::launch<64, 4>(x, pre, gamma, beta, y, rows, channels, eps, s, ob16);
+    case 5: case 6: return norm::launch<64, 6>(x, pre, gamma, beta, y, rows, channels, eps, s, ob16);
+    default: return norm::launch<64, 8>(x, pre, gamma, beta, y, rows, channels, eps, s, ob16);
   }
+}
+
+extern "C" int32_t dlwp_layernorm_prebias_f32(const float* x, const float* pre, const float* gamma, const float* beta,
+                                              float* y, int64_t rows, int32_t channels, float eps, void* stream) {
+  return layernorm_prebias(x, pre, gamma, beta, y, rows, channels, eps, stream, false);
+}
+
+// the same LayerNorm with a bf16 result (y_bf16 [rows][channels], round to nearest even): the input of a bf16-form Linear
+extern "C" int32_t dlwp_layernorm_prebias_bf16out(const float* x, const float* pre, const float* gamma, const float* beta,
+                                                  void* y_bf16, int64_t rows, int32_t channels, float eps, void* stream) {
+  return layernorm_prebias(x, pre, gamma, beta, reinterpret_cast<float*>(y_bf16), rows, channels, eps, stream, true);
 }
 
 extern "C" int32_t dlwp_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,

@@ -117,6 +117,8 @@ SIGNATURES = {
     "dlwp_layernorm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_float, c_void_p]),
     "dlwp_layernorm_prebias_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_float,
                                              c_void_p]),
+    "dlwp_layernorm_prebias_bf16out": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_float,
+                                                 c_void_p]),
     "dlwp_layernorm_nhwc_to_nchw_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64, c_int32,
                                                   c_float, c_void_p]),
     "dlwp_afno_merge_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
@@ -214,7 +216,7 @@ class KernelTimer:
         import torch
 
         lib = load()
-        names = self.names or [n for n in SIGNATURES if n.endswith(("_f32", "_bf16", "_f16x3", "_bf16_io"))]
+        names = self.names or [n for n in SIGNATURES if n.endswith(("_f32", "_bf16", "_f16x3", "_bf16_io", "_bf16out"))]
         for name in names:
             fn = getattr(lib, name)
             self._saved[name] = fn

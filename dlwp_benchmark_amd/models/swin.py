@@ -96,8 +96,8 @@ class _Block(nn.Module):
             prec = ops.form_precision(self.linear_form)
             if pend is not None:
                 x.add_(pend)
-            qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), self.attn.qkv,
-                             precision=prec)
+            qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps,
+                                            out_dtype=torch.bfloat16 if prec == "bf16" else None), self.attn.qkv, precision=prec)
             a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.relative_position_bias_table, spec,
                                      precision=self.attention_precision)
             return ops.attention_block_tail(x, a, self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2, precision=prec), None

@@ -641,8 +641,10 @@ def afno_block_tail(f_cf: torch.Tensor, l_cf: torch.Tensor, x_nhwc: torch.Tensor
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
-               pre_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """LayerNorm over the last dimension (any leading shape); pre_bias [C] is added to x before the statistics."""
+               pre_bias: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """LayerNorm over the last dimension (any leading shape); pre_bias [C] is added to x before the statistics.
+    out_dtype=torch.bfloat16: the result rounded to bfloat16 (dlwp_layernorm_prebias_bf16out) -- for a bf16-form Linear, which
+    would round it the same way itself."""
     _lib.require_cuda_tensor(x, "x")
     from . import training as _T
     if _T.wants_grad(x, weight, bias, pre_bias):     # training: the pointwise layers are torch operators (training.py)
@@ -650,13 +652,14 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     x = x.contiguous()
     c = x.shape[-1]
     rows = x.numel() // c
-    y = torch.empty_like(x)
+    ob16 = out_dtype == torch.bfloat16
+    y = torch.empty_like(x, dtype=torch.bfloat16) if ob16 else torch.empty_like(x)
     lib = _lib.load()
+    name = "dlwp_layernorm_prebias_bf16out" if ob16 else "dlwp_layernorm_prebias_f32"
     with torch.cuda.device(x.device):
-        _lib.check(lib.dlwp_layernorm_prebias_f32(x.data_ptr(), pre_bias.contiguous().data_ptr() if pre_bias is not None else None,
-                                                  weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
-                                                  y.data_ptr(), rows, c, float(eps), _lib.stream_ptr()),
-                   "dlwp_layernorm_prebias_f32")
+        _lib.check(getattr(lib, name)(x.data_ptr(), pre_bias.contiguous().data_ptr() if pre_bias is not None else None,
+                                      weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+                                      y.data_ptr(), rows, c, float(eps), _lib.stream_ptr()), name)
     return y
 
 
@@ -721,8 +724,8 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
     x_bf16 = x.dtype == torch.bfloat16
     o_bf16 = out_dtype == torch.bfloat16 or (out is not None and out.dtype == torch.bfloat16)
     if x_bf16 or o_bf16:
-        if precision != "bf16" or (x_bf16 and o_bf16) or (o_bf16 and resid is not None):
-            raise _lib.DlwpError("linear: a bfloat16 tensor is taken on ONE side, by precision='bf16', without a residual on a bfloat16 output")
+        if precision != "bf16" or (o_bf16 and resid is not None):
+            raise _lib.DlwpError("linear: bfloat16 tensors are taken by precision='bf16', without a residual on a bfloat16 output")
         if not x.is_cuda:
             raise _lib.DlwpError("linear: x must be a CUDA tensor")
     else:
@@ -850,9 +853,10 @@ def attention_block_tail(x: torch.Tensor, attn_out: torch.Tensor, proj: torch.nn
     panguweather.py:318-322), IN PLACE on x: three dlwp_linear_f32 launches (bias, GELU and both residual adds in the GEMM
     epilogues) and one LayerNorm."""
     linear(attn_out, proj, resid=x, out=x, precision=precision)
-    n2 = layer_norm(x, norm2.weight, norm2.bias, norm2.eps)
-    # bf16 form: the hidden activation crosses HBM as bfloat16 (fc2 rounds its input to bf16 anyway: bit-identical)
-    hid = linear(n2, fc1, act=1, precision=precision, out_dtype=torch.bfloat16 if precision == "bf16" else None)
+    # bf16 form: LayerNorm output and hidden activation cross HBM as bfloat16 (their consumers round to bf16 anyway: bit-identical)
+    b16 = torch.bfloat16 if precision == "bf16" else None
+    n2 = layer_norm(x, norm2.weight, norm2.bias, norm2.eps, out_dtype=b16)
+    hid = linear(n2, fc1, act=1, precision=precision, out_dtype=b16)
     linear(hid, fc2, resid=x, out=x, precision=precision)
     return x
 

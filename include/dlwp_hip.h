@@ -339,7 +339,8 @@ int32_t dlwp_linear_bf16(const float* x_dev, const void* packed_dev, const float
 /* dlwp_linear_bf16 with a bf16 TENSOR on one side -- how the MLP of a block hands its hidden activation from fc1 to fc2 in the
  * bf16 form (swin_transformer.py:21-39 under autocast): x_is_bf16: x_dev is bf16 [rows][in] (the values dlwp_linear_bf16 would round
  * its fp32 input to: bit-identical result); out_is_bf16: out_dev is bf16 [rows][out], rounded to nearest even after bias / GELU,
- * resid_dev must be NULL.  Exactly one of the two flags. */
+ * resid_dev must be NULL.  At least one of the two flags.  dlwp_layernorm_prebias_bf16out (below the LayerNorm entry points)
+ * produces such an input. */
 int32_t dlwp_linear_bf16_io(const void* x_dev, const void* packed_dev, const float* bias_dev, const float* resid_dev,
                             void* out_dev, int64_t rows, int32_t in_features, int32_t out_features, int32_t act,
                             int32_t x_is_bf16, int32_t out_is_bf16, void* stream);
@@ -402,6 +403,11 @@ int32_t dlwp_layernorm_f32(const float* x_dev, const float* gamma_dev, const flo
 int32_t dlwp_layernorm_prebias_f32(const float* x_dev, const float* pre_bias_dev, const float* gamma_dev,
                                    const float* beta_dev, float* y_dev, int64_t rows, int32_t channels, float eps,
                                    void* stream);
+/* The same LayerNorm with a bf16 result (y_bf16_dev [rows][channels], round to nearest even): the input of a bf16-form Linear
+ * (dlwp_linear_bf16_io with x_is_bf16), which would round the fp32 result the same way -- bit-identical, half the bytes. */
+int32_t dlwp_layernorm_prebias_bf16out(const float* x_dev, const float* pre_bias_dev, const float* gamma_dev,
+                                       const float* beta_dev, void* y_bf16_dev, int64_t rows, int32_t channels, float eps,
+                                       void* stream);
 
 /* FourCastNet block glue fused with the layout change the FFT needs (models/fourcastnet/fourcastnet.py
  * :180-193 around AFNO2D :78-127).  x is token-major [B, tokens, C] ("NHWC"), y / f / l channel-major

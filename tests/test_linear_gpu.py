@@ -290,3 +290,25 @@ def test_linear_bf16_hidden_handover_is_bit_identical(rows, c, hid):
     assert torch.equal(y16, y32)
     with pytest.raises(Exception):
         ops.linear(h16, fc2, precision="fp32")
+
+
+@pytest.mark.parametrize("rows,c,hid", [(4096, 96, 384), (1000, 192, 768), (77, 384, 1536)])
+def test_layernorm_bf16_output_feeds_the_bf16_linear_bit_identically(rows, c, hid):
+    """dlwp_layernorm_prebias_bf16out + dlwp_linear_bf16_io (bf16 x, bf16 or fp32 out): LayerNorm rounded to bf16 by its own
+    kernel, then fc1 -- the same bits as fp32 LayerNorm -> dlwp_linear_bf16 (which rounds its input itself)."""
+    from dlwp_benchmark_amd import ops
+
+    fc1 = _linear(c, hid, True, seed=rows)
+    g = torch.Generator().manual_seed(rows + c)
+    x = (torch.randn(rows, c, generator=g) * 1.7 + 0.2).to(DEV)
+    gamma = (1.0 + 0.2 * torch.randn(c, generator=g)).to(DEV)
+    beta = (0.2 * torch.randn(c, generator=g)).to(DEV)
+    pre = (0.1 * torch.randn(c, generator=g)).to(DEV)
+    with torch.no_grad():
+        n32 = ops.layer_norm(x, gamma, beta, 1e-5, pre_bias=pre)
+        n16 = ops.layer_norm(x, gamma, beta, 1e-5, pre_bias=pre, out_dtype=torch.bfloat16)
+        assert n16.dtype == torch.bfloat16 and torch.equal(n16, n32.bfloat16())
+        a = ops.linear(n32, fc1, act=1, precision="bf16")
+        b = ops.linear(n16, fc1, act=1, precision="bf16")
+        c16 = ops.linear(n16, fc1, act=1, precision="bf16", out_dtype=torch.bfloat16)
+    assert torch.equal(a, b) and torch.equal(c16, a.bfloat16())
