@@ -337,7 +337,8 @@ def _other_roofline(cls, cfg, batch, h, w, summ, prec):
         fl = 4.0 * tokens * c * hid                      # fc1 + fc2
         by = 4.0 * tokens * c * 4                        # f, l, x read + x written (one read + one write per operand plane)
         ach = by / (avg * 1e-3) / 1e9
-        return {"kernel": "token_mlp_kernel<MERGE, NEXT> via dlwp_afno_block_tail_f32 (irfft out + skips + LN2 + fc1/GELU/fc2 + next LN1)",
+        via = "dlwp_afno_block_tail_f16x3" if any(k[0] == "dlwp_afno_block_tail_f16x3" for k, _ in tail) else "dlwp_afno_block_tail_f32"
+        return {"kernel": f"token_mlp_kernel<MERGE, NEXT> via {via} (irfft out + skips + LN2 + fc1/GELU/fc2 + next LN1)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": by, "avg_launch_ms": avg, "launches_per_rollout": n,
                 "mfma_view": {"algorithmic_flops_per_launch": fl, "achieved_TFLOPs": fl / (avg * 1e-3) / 1e12,
