@@ -324,6 +324,26 @@ def test_f16x3_range_guard_repeats_on_bf16x6():
     hip.verify()
 
 
+@pytest.mark.parametrize("nprog", [2, 3, 4])
+def test_fno_register_feedback_with_several_prognostic_channels(nprog):
+    """Persistent rollout with the step's input and residual kept in registers (TrunkParams.feed_regs: no constants, no
+    prescribed channels, context 1, <= 4 prognostic channels): the lanes of channel group g carry channel g, the other lane
+    groups zeros.  2, 3 and 4 channels (3 -> the projection's FMA layer is built for 4 outputs) over 12 steps against the
+    oracle, and against the same rollout issued step by step (launch_form 1: every step reloads its input from memory)."""
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    kw = dict(NS_KW, prognostic_channels=nprog)
+    ref, hip = _make_pair(**kw)
+    _, _, prog = navier_stokes(8, 13, 64, 64, channels=nprog)
+    p = prog.to(_dev())
+    stepwise = copy.deepcopy(hip).set_execution_form(launch_form=1)   # (before the first call: a plan cannot be copied)
+    with torch.no_grad():
+        want = ref(prognostic=prog[:2])
+    got = hip(prognostic=p)
+    assert max(per_step_rel_l2(got[:2], want)) <= TOL
+    assert torch.equal(stepwise(prognostic=p), got)
+
+
 def test_tfno_matches_fno_with_reconstructed_weights():
     """TFNO2DModule (fno.py:109-146) = the FNO path on the dense weight rebuilt from its Tucker factors: same
     trajectory as an FNO2DModule loaded with the reconstructed tensors, and as the oracle on them."""
