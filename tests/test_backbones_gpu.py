@@ -401,18 +401,20 @@ def _horizon_cases():
 
 
 @pytest.mark.parametrize("tag", _horizon_cases())
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16", "bf16all"])
 def test_full_width_rollout_at_configured_horizon(tag, precision):
     """BASELINE configs C3 / C4 / C5 at FULL width over their CONFIGURED horizons (12 / 20 / 5 steps, one initial
-    condition) against the trajectory of the real reference classes: fp32 path <= 1e-5 per step; bf16 window attention
-    (the precision BASELINE names for C3 / C5) within its stated 5e-3 bound at every lead time."""
+    condition) against the trajectory of the real reference classes: fp32 path <= 1e-5 per step -- with the Linear / MLP
+    products from three-part bf16 splits ("fp32") and from two-part f16 splits ("f16x3"); bf16 window attention (the
+    precision BASELINE names for C3 / C5) within its stated 5e-3 bound at every lead time, alone ("bf16") and with bf16
+    Linear operands and the bf16 hand-over of LayerNorm outputs and the MLP's hidden activation ("bf16all")."""
     import dlwp_benchmark_amd.models as M
     from dlwp_benchmark_amd.weights import fill_state_dict
     from oracle.make_golden import HORIZON_CASES, MODEL_CASES, model_inputs
 
     base, frames, stride = HORIZON_CASES[tag]
     family, cfg, (batch, _), gain = MODEL_CASES[base]
-    if precision == "bf16" and family == "afno":
+    if precision in ("bf16", "bf16all") and family == "afno":
         pytest.skip("FourCastNet has no attention")
     name, _ = _product_class(family)
     g = load_golden(f"model_{tag}")
@@ -420,8 +422,15 @@ def test_full_width_rollout_at_configured_horizon(tag, precision):
     sha = fill_state_dict(model, gain=gain)
     assert sha == str(g["sha"]), "filler drifted: regenerate fixtures"
     model = model.to("cuda:0").eval()
-    if precision == "bf16":
+    if precision in ("bf16", "bf16all"):
         model.set_attention_precision("bf16")
+    if precision == "bf16all":
+        model.set_linear_form("bf16")
+    if precision == "f16x3":
+        if hasattr(model, "set_linear_form"):
+            model.set_linear_form("f16x3")
+        if hasattr(model, "set_mlp_form"):
+            model.set_mlp_form("f16x3")
     constants, prescribed, prognostic = model_inputs(base, cfg, batch, frames)
     dev = lambda t: t.to("cuda:0") if t is not None else None
     got = model(constants=dev(constants), prescribed=dev(prescribed), prognostic=dev(prognostic))
@@ -431,4 +440,4 @@ def test_full_width_rollout_at_configured_horizon(tag, precision):
     assert got.shape == want.shape
     errs = per_step_rel_l2(got, want)
     print(tag, precision, "per-step rel L2:", ["%.2e" % e for e in errs])
-    assert max(errs) <= (5e-3 if precision == "bf16" else TOL), errs
+    assert max(errs) <= (5e-3 if precision in ("bf16", "bf16all") else TOL), errs
