@@ -1608,30 +1608,41 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     DLWP_STAMP();
     // ---- P1: partial H-direction DFT of the own rows, columns (ky = wave, wave + ROWS, ..; c)
     for (int ky = wave; ky < M2; ky += ROWS) {
+      // the four accumulator chains (2 channel halves x re / im) interleaved: a dependent fp32 matrix instruction waits ~40 cycles
+      f32x4 dre[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dim[2] = {dre[0], dre[0]};
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        f32x4 dre = {0.f, 0.f, 0.f, 0.f}, dim = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < KS1; ++s) {
 #pragma unroll
-        for (int s = 0; s < KS1; ++s) {
+        for (int nt = 0; nt < 2; ++nt) {
           const float b = s_y[(2 * s + (g >> 1)) * kSyStride + (2 * ky + (g & 1)) * C + 16 * nt + j];
-          dre = mfma16x16x4(a_re[s], b, dre);
-          dim = mfma16x16x4(a_im[s], b, dim);
-        }
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int r = 4 * g + r4;
-          if (r < M1) {
-            float* dst = xp_mine + (long long)(ky * M1 + r) * 64 + 16 * nt + j;
-            if (LL) {
-              st_xchg(dst, dre[r4], fast);
-              st_xchg(dst + 32, dim[r4], fast);
-            } else {
-              st_sc1(dst, dre[r4]);
-              st_sc1(dst + 32, dim[r4]);
-            }
-          }
+          dre[nt] = mfma16x16x4(a_re[s], b, dre[nt]);
+          dim[nt] = mfma16x16x4(a_im[s], b, dim[nt]);
         }
       }
+      // one wave-uniform decision for all 16 stores of the wave (st_xchg branched per store)
+      auto publish = [&](auto fastc) {
+        constexpr bool FAST = decltype(fastc)::value;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = 4 * g + r4;
+            if (r < M1) {
+              float* dst = xp_mine + (long long)(ky * M1 + r) * 64 + 16 * nt + j;
+              if constexpr (!LL) {
+                st_sc1(dst, dre[nt][r4]);
+                st_sc1(dst + 32, dim[nt][r4]);
+              } else if constexpr (FAST) {
+                dst[0] = dre[nt][r4];
+                dst[32] = dim[nt][r4];
+              } else {
+                __hip_atomic_store(dst, dre[nt][r4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 32, dim[nt][r4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          }
+      };
+      if (fast) publish(std::true_type{}); else publish(std::false_type{});
     }
     DLWP_STAMP();
     target += (unsigned)G;
