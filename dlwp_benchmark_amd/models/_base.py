@@ -23,6 +23,90 @@ class HipBackbone(torch.nn.Module):
         self.step_graphs = False     # replay one_step as a HIP graph (launch-bound backbones), see graphs.py
         self._graphed = None
 
+    # ---- precision forms (per-module state, no process-wide switch) ------------------------------------------------
+    # name -> (attention precision, Linear form, block-tail MLP form).  "fp32" is the parity path of every mirror;
+    # "f16x3" is fp32-grade too (two-part f16 splits); "bf16" is what the reference gets from
+    # autocast(bfloat16) and what BASELINE.json names for the Swin and Pangu configs.
+    COMPUTE_PRECISIONS = {"fp32": ("fp32", "bf16x6", "bf16x6"), "f16x3": ("fp32", "f16x3", "f16x3"),
+                          "bf16attn": ("bf16", "bf16x6", "bf16x6"), "bf16": ("bf16", "bf16", "bf16x6")}
+
+    def _set_on_submodules(self, attr: str, value) -> int:
+        n = 0
+        for m in self.modules():
+            if attr in m.__dict__:
+                setattr(m, attr, value)
+                n += 1
+        self._graphed = None        # a captured step graph baked the OLD kernels in: re-capture
+        return n
+
+    def set_attention_precision(self, precision: str):
+        """"fp32" (default, parity path; "fp32_mfma" / "bf16x6" force one of its two fp32-accurate forms) or "bf16"
+        (bf16 MFMA operands, fp32 accumulate / softmax)."""
+        if precision not in ("fp32", "fp32_mfma", "bf16x6", "bf16"):
+            raise _lib.DlwpError(f"unknown attention precision {precision!r}")
+        self._set_on_submodules("attention_precision", precision)
+        return self
+
+    def set_linear_form(self, form: str):
+        """"bf16x6" (default): the blocks' Linears run dlwp_linear_f32 (fp32-accurate on the bf16 matrix pipe, fused epilogues);
+        "f16x3": dlwp_linear_f16x3 (fp32-grade, two-part f16 splits); "bf16": dlwp_linear_bf16 (bf16 operands, fp32
+        accumulation -- nn.Linear under autocast(bfloat16)); "rocblas": torch's fp32 GEMMs (the cross-check)."""
+        from .. import ops
+
+        if form not in ops.LINEAR_FORMS:
+            raise _lib.DlwpError(f"unknown linear form {form!r}")
+        self._set_on_submodules("linear_form", form)
+        return self
+
+    def set_mlp_form(self, form: str):
+        """FourCastNet block tails: "bf16x6" (default; fp32 products from three-part bf16 splits) or "f16x3" (two-part f16
+        splits, dlwp_afno_block_tail_f16x3).  Both fp32-GEMM accurate."""
+        if form not in ("bf16x6", "f16x3"):
+            raise _lib.DlwpError(f"unknown MLP form {form!r}")
+        self._set_on_submodules("mlp_form", form)
+        return self
+
+    def set_compute_precision(self, name: str):
+        """ONE knob over the three above -- also the constructor kwarg `compute_precision` (a key the reference ignores:
+        every reference constructor swallows unknown keys through **kwargs, so a config that carries it still builds
+        there): "fp32" | "f16x3" | "bf16attn" | "bf16".  A drop-in user selects the config's named precision in
+        `configs/model/*.yaml` and never calls a setter."""
+        if name not in self.COMPUTE_PRECISIONS:
+            raise _lib.DlwpError(f"unknown compute_precision {name!r} (one of {sorted(self.COMPUTE_PRECISIONS)})")
+        attn, lin, mlp = self.COMPUTE_PRECISIONS[name]
+        self._set_on_submodules("attention_precision", attn)
+        self._set_on_submodules("linear_form", lin)
+        self._set_on_submodules("mlp_form", mlp)
+        self.compute_precision = name
+        return self
+
+    def _init_compute_precision(self, kwargs: dict):
+        """called at the end of a mirror's constructor with its **kwargs"""
+        cp = kwargs.get("compute_precision")
+        self.compute_precision = "fp32"
+        if cp is not None:
+            self.set_compute_precision(str(cp))
+
+    def invalidate_packed(self):
+        """Derived operands (packed bf16 / f16 weight images, FNO plans, step graphs) are keyed on (data_ptr, _version) of
+        their source parameters.  Writes through `.data` (EMA / init code: `p.data.copy_()`, `p.data.mul_()`) keep both --
+        call this after such writes.  `load_state_dict` and `_apply` (.to / .half / .float) call it themselves."""
+        from .. import ops
+
+        ops.bump_pack_epoch()       # part of every derived-operand key (ops.pack_epoch) and of _param_key below
+        self._graphed = None
+        return self
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_packed()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.invalidate_packed()
+        return r
+
     def set_step_graphs(self, on: bool = True):
         """Capture `one_step` into a HIP graph and replay it per rollout step (eval mode only)."""
         self.step_graphs = bool(on)
@@ -68,4 +152,6 @@ class HipBackbone(torch.nn.Module):
         return self._ws
 
     def _param_key(self):
-        return tuple((p._version, p.data_ptr()) for p in list(self.parameters()) + list(self.buffers()))
+        from .. import ops
+
+        return (ops.pack_epoch(),) + tuple((p._version, p.data_ptr()) for p in list(self.parameters()) + list(self.buffers()))

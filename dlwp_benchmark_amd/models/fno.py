@@ -237,6 +237,10 @@ class FNO2DModule(HipBackbone):
                self._debug_spin_limit, self.check)
         if self._plan is not None and key == self._plan_key:
             return self._plan
+        if self._plan is not None and self.check == "deferred":
+            # the sticky failure counters live in the plan: launches of the OLD plan that have not been verified yet are
+            # verified now (raises DLWP_ERR_TIMEOUT / DLWP_ERR_RANGE here), before a rebuild would drop them
+            self.verify()
         self._destroy_plan()
         lib = _lib.load()
         f = self.fno

@@ -141,16 +141,7 @@ class FourCastNet(HipBackbone):
                                             hard_thresholding_fraction) for _ in range(depth)])
         self.norm = ops.HipLayerNorm(embed_dim, eps=1e-6)   # in the reference state dict, never applied (:283-293)
         self.head = nn.Linear(embed_dim, self.out_chans * self.patch_size[0] * self.patch_size[1], bias=False)
-
-    def set_mlp_form(self, form: str):
-        """"bf16x6" (default): the block tails' fp32 products from three-part bf16 splits (six matrix instructions each);
-        "f16x3": from two-part f16 splits (three) -- dlwp_afno_block_tail_f16x3.  Both fp32-GEMM accurate.  Per-module state."""
-        if form not in ("bf16x6", "f16x3"):
-            raise _lib.DlwpError(f"unknown MLP form {form!r}")
-        for m in self.modules():
-            if hasattr(m, "mlp_form"):
-                m.mlp_form = form
-        return self
+        self._init_compute_precision(kwargs)     # `compute_precision: bf16` in configs/model/*.yaml (HipBackbone.set_compute_precision)
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:
         b = x.shape[0]

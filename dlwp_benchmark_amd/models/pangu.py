@@ -251,27 +251,7 @@ class PanguWeather(HipBackbone):
         self.upsample = _UpSample(embed_dim * 2, embed_dim, res2, res)
         self.layer4 = _BasicLayer(embed_dim, res, 2, num_heads[3], window_size)
         self.patchrecovery2d = _PatchRecovery2D((n_lat, n_lon), patch_size, 2 * embed_dim, prognostic_channels)
-
-    def set_attention_precision(self, precision: str):
-        """"fp32" (default, parity path; "fp32_mfma" / "bf16x6" force one of its two fp32-accurate forms) or "bf16"
-        (bf16 MFMA operands, fp32 accumulate / softmax).  Per-module state, no process-wide switch."""
-        if precision not in ("fp32", "fp32_mfma", "bf16x6", "bf16"):
-            raise _lib.DlwpError(f"unknown attention precision {precision!r}")
-        for m in self.modules():
-            if hasattr(m, "attention_precision"):
-                m.attention_precision = precision
-        return self
-
-    def set_linear_form(self, form: str):
-        """"bf16x6" (default): the blocks' Linears run dlwp_linear_f32 (fp32-accurate on the bf16 matrix pipe, fused epilogues);
-        "rocblas": torch's fp32 GEMMs (each is the other's cross-check); "bf16": dlwp_linear_bf16 (bf16 operands, fp32
-        accumulation -- nn.Linear under autocast(bfloat16)).  Per-module state."""
-        if form not in ops.LINEAR_FORMS:
-            raise _lib.DlwpError(f"unknown linear form {form!r}")
-        for m in self.modules():
-            if hasattr(m, "linear_form"):
-                m.linear_form = form
-        return self
+        self._init_compute_precision(kwargs)     # `compute_precision: bf16` in configs/model/*.yaml (HipBackbone.set_compute_precision)
 
     def one_step(self, x: torch.Tensor) -> torch.Tensor:
         """panguweather.py:512-535 (`forward_one_step`)."""
@@ -314,7 +294,7 @@ class PanguWeather(HipBackbone):
         first through the residual operand); the output width is padded to a multiple of 4 with zero columns."""
         conv = self.patchrecovery2d.conv
         w, bias = conv.weight, conv.bias
-        key = (w.data_ptr(), w._version, str(w.device), bias.data_ptr(), bias._version)
+        key = (w.data_ptr(), w._version, str(w.device), bias.data_ptr(), bias._version, ops.pack_epoch())
         halves = self.__dict__.get("_recover_lin")
         if halves is None or halves[0] != key:
             cc, cg = x.shape[-1], w.shape[1]

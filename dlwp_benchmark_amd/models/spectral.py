@@ -11,6 +11,12 @@ from torch import nn
 from .. import lib as _lib
 
 
+def _ops_epoch():
+    from .. import ops
+
+    return ops.pack_epoch()
+
+
 class SpectralConv2d(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, modes1: int, modes2: int):
         super().__init__()
@@ -41,7 +47,7 @@ class SpectralConv2d(nn.Module):
 
     def _get_plan(self, h, w, device):
         key = (h, w, str(device), self.weights1._version, self.weights1.data_ptr(), self.weights2._version,
-               self.weights2.data_ptr())
+               self.weights2.data_ptr(), _ops_epoch())
         if self._plan is not None and key == self._plan_key:
             return self._plan
         self._destroy_plan()

@@ -209,30 +209,10 @@ class SwinTransformer(HipBackbone):
                 nn.ConvTranspose2d(ch if idx == 0 else ch * 2, ch if i_layer == 0 else ch // 2, kernel_size=k, stride=k),
                 nn.GELU()))
         self.final = nn.Conv2d(embed_dim, prognostic_channels, kernel_size=1)
+        self._init_compute_precision(kwargs)     # `compute_precision: bf16` in configs/model/*.yaml (HipBackbone.set_compute_precision)
 
     def train(self, mode: bool = True):
         super().train(mode)
-        return self
-
-    def set_attention_precision(self, precision: str):
-        """"fp32" (default, parity path; "fp32_mfma" / "bf16x6" force one of its two fp32-accurate forms) or "bf16"
-        (bf16 MFMA operands, fp32 accumulate / softmax).  Per-module state, no process-wide switch."""
-        if precision not in ("fp32", "fp32_mfma", "bf16x6", "bf16"):
-            raise _lib.DlwpError(f"unknown attention precision {precision!r}")
-        for m in self.modules():
-            if hasattr(m, "attention_precision"):
-                m.attention_precision = precision
-        return self
-
-    def set_linear_form(self, form: str):
-        """"bf16x6" (default): the blocks' Linears run dlwp_linear_f32 (fp32-accurate on the bf16 matrix pipe, fused epilogues);
-        "rocblas": torch's fp32 GEMMs (each is the other's cross-check); "bf16": dlwp_linear_bf16 (bf16 operands, fp32
-        accumulation -- nn.Linear under autocast(bfloat16)).  Per-module state."""
-        if form not in ops.LINEAR_FORMS:
-            raise _lib.DlwpError(f"unknown linear form {form!r}")
-        for m in self.modules():
-            if hasattr(m, "linear_form"):
-                m.linear_form = form
         return self
 
     def _token_decoder(self):

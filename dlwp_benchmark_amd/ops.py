@@ -526,6 +526,21 @@ def token_mlp_supported(channels: int, hidden: int) -> bool:
     return int(_lib.load().dlwp_token_mlp_packed_bytes(int(channels), int(hidden))) > 0
 
 
+# Derived operands are keyed on (data_ptr, _version) of their source parameters; writes through `.data` change neither.
+# HipBackbone.invalidate_packed() (called by load_state_dict / _apply, and by users after `.data` writes) bumps this epoch,
+# which is part of every key below: all packed images, plans and step graphs of the process are re-derived on next use.
+_PACK_EPOCH = [0]
+
+
+def pack_epoch() -> int:
+    return _PACK_EPOCH[0]
+
+
+def bump_pack_epoch() -> int:
+    _PACK_EPOCH[0] += 1
+    return _PACK_EPOCH[0]
+
+
 class TokenMlpWeights:
     """fc1 / fc2 weights of a token MLP in the operand layout of dlwp_token_mlp_f32, re-packed on the device
     whenever a parameter has been written to (optimizer step, load_state_dict, .to()).  With `ln_weight` / `ln_bias`
@@ -541,7 +556,7 @@ class TokenMlpWeights:
         """merged=True: the k-slot order afno_block_tail wants (a different permutation of W1's columns);
         f16x3=True: the two f16 images of the f16x3 product form (afno_block_tail(form="f16x3"))."""
         extra = [t for t in (ln_weight, ln_bias, b1) if t is not None]
-        key = tuple((t.data_ptr(), t._version) for t in (w1, w2, *extra)) + (str(w1.device), ln_weight is not None, merged, f16x3)
+        key = tuple((t.data_ptr(), t._version) for t in (w1, w2, *extra)) + (str(w1.device), ln_weight is not None, merged, f16x3, pack_epoch())
         if key != self._key:
             hid, c = w1.shape
             if tuple(w2.shape) != (c, hid):
@@ -686,7 +701,7 @@ class LinearWeights:
         return self._get(weight, "dlwp_linear_pack_f32")
 
     def _get(self, weight: torch.Tensor, packer: str) -> torch.Tensor:
-        key = (weight.data_ptr(), weight._version, str(weight.device))
+        key = (weight.data_ptr(), weight._version, str(weight.device), pack_epoch())
         if key != self._key:
             n, k = weight.shape
             lib = _lib.load()
@@ -812,7 +827,7 @@ class ConvAsLinear:
 
     def refresh(self):
         w, b = self.conv.weight, self.conv.bias
-        key = (w.data_ptr(), w._version, str(w.device), None if b is None else (b.data_ptr(), b._version))
+        key = (w.data_ptr(), w._version, str(w.device), None if b is None else (b.data_ptr(), b._version), pack_epoch())
         if key == self._key:
             return
         with torch.no_grad():

@@ -14,15 +14,23 @@ import torch
 
 
 def _none_if_sentinel(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """The dataset marks an absent input with a NaN tensor (datasets.py:317, :378)."""
-    if t is None or (t.numel() > 0 and torch.isnan(t.reshape(-1)[0])):
+    """The dataset marks an absent input with a NaN tensor (datasets.py:317, :378); the evaluation loop decides with
+    `.isnan().any()` (scripts/evaluate.py:213-215, train.py:180-181): ANY NaN makes the whole input absent."""
+    if t is None or (t.numel() > 0 and bool(torch.isnan(t).any())):
         return None
     return t
 
 
 class DeviceStager:
-    def __init__(self, batches: Iterable[Tuple], device):
+    """`split_size` restates `.split(split_size)` of the evaluation loop (evaluate.py:212-217, with
+    split_size = batch_size // gradient_accumulation_steps): every uploaded batch is handed on as consecutive
+    sub-batches of at most `split_size` samples along dim 0 (views of ONE upload; None inputs stay None)."""
+
+    def __init__(self, batches: Iterable[Tuple], device, split_size: Optional[int] = None):
         self.batches = batches
+        self.split_size = int(split_size) if split_size else None
+        if self.split_size is not None and self.split_size < 1:
+            raise ValueError("split_size must be >= 1")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("DeviceStager stages onto a GPU")
@@ -58,4 +66,9 @@ class DeviceStager:
             for t in cur:
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream(self.device))
-            yield tuple(cur)
+            if self.split_size is None:
+                yield tuple(cur)
+                continue
+            n = max(t.shape[0] for t in cur if t is not None)
+            for a in range(0, n, self.split_size):
+                yield tuple(t[a:a + self.split_size] if t is not None else None for t in cur)

@@ -195,7 +195,7 @@ def window_attention_torch(qkv: torch.Tensor, qkv_bias, table: torch.Tensor, spe
     pads = (0, 0, lft, plon - lon - lft, t, plat - lat - t, f, ppl - pl - f)
     if any(pads):
         # zero-padded tokens enter the qkv Linear as zeros: their q, k, v are the bias
-        x = F.pad(x - qkv_bias, pads) + qkv_bias
+        x = F.pad(x - qkv_bias, pads) + qkv_bias if qkv_bias is not None else F.pad(x, pads)
     sf = tuple(int(s) for s in spec.shift_fwd)
     if any(sf):
         x = torch.roll(x, shifts=(-sf[0], -sf[1], -sf[2]), dims=(1, 2, 3))

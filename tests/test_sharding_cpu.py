@@ -169,3 +169,54 @@ def test_two_rank_metric_allreduce_matches_whole_batch_oracle():
         # scales in float32, hence 1e-7)
         assert torch.allclose(got_rmse, torch.from_numpy(rmse), rtol=1e-7, atol=0), f"rank {r} RMSE"
         assert torch.allclose(got_acc, torch.from_numpy(acc), rtol=1e-7, atol=1e-9), f"rank {r} ACC"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py --config C3 / C4 / C5 under world > 1 (reference call site scripts/evaluate.py:205-244): the SAME
+# make_runner / timed_region the GPU run uses, with the stand-in backbone and the CPU stand-in of the sums kernel --
+# warm-up, reset, K timed rollouts with per-rank accumulation, ONE all-reduce, max-over-ranks clock.
+# ---------------------------------------------------------------------------------------------------------------
+def _bench_flow_worker(rank, world, port, ret, collect):
+    import argparse
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        presc, prog = _inputs(3, 6)
+        g = torch.Generator().manual_seed(100 + rank)            # every rank its own shard of initial conditions
+        prog = prog + 0.1 * torch.randn(prog.shape, generator=g)
+        args = argparse.Namespace(gather_chunks=2, collect=collect)
+        scorer = _CpuSumsMetrics(torch.zeros(8), None, None)
+        step0, finish, acc = bench.make_runner(ToyBackbone(), world, rank, args, prog, 8, 16, scorer=scorer)
+        dt = bench.timed_region(lambda: step0(prescribed=presc), finish, steps=3, warmup=2, dist=dist, device="cpu", backend="gloo")
+        ret[rank] = (dt, acc["samples"], acc["scores"]["rmse"] if acc["scores"] else None, acc["out"], prog)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("collect", ["metrics", "gather"])
+def test_two_rank_bench_control_flow(collect):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000) + (7 if collect == "gather" else 0)
+    mp.spawn(_bench_flow_worker, args=(world, port, ret, collect), nprocs=world, join=True)
+    presc, _ = _inputs(3, 6)
+    assert ret[0][0] == ret[1][0] > 0                          # ONE clock: the max over ranks, identical on both
+    progs = torch.cat([ret[r][4] for r in range(world)])
+    want = ShardedRollout(ToyBackbone(), world_size=1)(prescribed=torch.cat([presc, presc]), prognostic=progs)
+    if collect == "metrics":
+        assert ret[0][1] == 3 * 3                              # warm-up sums were reset: 3 timed rollouts x 3 samples
+        # scores over ALL ranks' samples (3 identical rollouts accumulate to the same mean)
+        rmse = torch.sqrt(((want.double() - progs[:, 1:].double()) ** 2).mean(dim=(0, 3, 4)))
+        for r in range(world):
+            assert torch.allclose(ret[r][2], rmse, rtol=1e-12)
+    else:
+        for r in range(world):
+            assert torch.equal(ret[r][3], want)                # every rank holds the rank-major global trajectory
