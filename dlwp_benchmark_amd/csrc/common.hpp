@@ -399,47 +399,114 @@ __device__ __forceinline__ f32x4 mfma_bf16x6(const u32x4 (&a)[3], const u32x4 (&
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp32 GEMM on the f16 matrix instructions ("f16x3", round 2): half the matrix instructions and less than half the
-// split work of bf16x6, for products that are still fp32-grade (1e-7 relative in a K = 256 GEMM, numpy emulation in
-// tests/test_f16x3_emulation.py) as long as |x| < 65504:
-//   x = xh + xm,  xh = f16(x), xm = f16(x - xh)              (11 + 11 significant bits; 5 VALU slots per PAIR: v_cvt_pk_f16_f32,
-//   w = wh + wm,  wh = f16(w), wm' = f16((w - wh) * 2^11)      two v_fma_mix_f32, v_cvt_pk_f16_f32, v_pk_mul_f16)
-//   w x ~= wm' * (xh * 2^-11) + wh * xm + wh * xh              (dropped: wm xm <= 2^-22 |w x|)
-// The weight residual is stored SCALED (host side, free) so that it is a normal f16 number for any weight magnitude; its
-// partner xs = xh * 2^-11 is exact unless |x| < 0.125, where the bits it loses are below 2^-25 of an O(1) activation.
-// MFMA operands and the conversions keep f16 subnormals (hipcc's default float_denorm_mode_16_64 = 3).
+// fp32 GEMM on the f16 matrix instructions ("f16x3", round 2; residual scaling completed in round 3): half the matrix
+// instructions and less than half the split work of bf16x6, for products that are fp32-grade (1e-7 relative in a K = 256 GEMM,
+// numpy emulation in tests/test_f16x3_emulation.py) for 2^-14 <= |x| < 65504 -- and degrade gracefully below (absolute 2^-36):
+//   x = xh + xm,  xh = f16(x),        xm' = f16((x - xh) * 2^11)      (11 + 11 significant bits; 5 VALU slots per PAIR:
+//   w = wh + wm,  wh = f16(w * 2^s),  wm' = f16((w * 2^s - wh) * 2^11)  v_cvt_pk_f16_f32, two v_fma_mix_f32, v_fma_mixlo/hi_f16)
+//   2^(11+s) w x ~= wm' * xh + wh * xm' + (wh * 2^11) * xh            (dropped: wm xm <= 2^-22 |w x|)
+// BOTH residuals are stored SCALED by 2^11, so neither is an f16 subnormal at any magnitude its leading part represents (round
+// 2 left the activation residual unscaled: an absolute floor of 3e-8 per activation, i.e. 2e-5 relative for activations of
+// 1e-3 -- VERDICT r02, tests/test_f16x3_lowend_gpu.py).  The three products then sit at one scale, 2^(11+s) times the true one,
+// in ONE accumulator: the leading product takes whB = wh * 2^11 (exact; formed from wh by v_pk_mul_f16 where an operand is read,
+// or stored as a third image where the table is small), and the consumer multiplies by 2^-(11+s) where it adds the bias (an FMA
+// in place of an add).  s is chosen per weight matrix when it is packed so that max |w| 2^s is in [8, 16): whB <= 2^15, no
+// overflow at any weight magnitude.  MFMA operands and the conversions keep f16 subnormals (hipcc's default
+// float_denorm_mode_16_64 = 3).
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+
+constexpr float kF16ResidualScale = 2048.0f;          // 2^11
+constexpr float kF16OutputScale = 1.0f / 2048.0f;     // what the accumulator of an f16x3 product chain is multiplied by (times 2^-s)
 
 __device__ __forceinline__ f32x4 mfma16x16x32_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// split of a pair of floats into the three B operands of f16x3: h = (xh0, xh1), s = h * 2^-11, m = (xm0, xm1)
-__device__ __forceinline__ void split_f16_pair(float x0, float x1, unsigned& h, unsigned& s, unsigned& m) {
+// split of a pair of floats into the two f16x3 operands: h = (xh0, xh1), m = (xm0', xm1') with xm' = f16((x - xh) * 2^11)
+__device__ __forceinline__ void split_f16_pair(float x0, float x1, unsigned& h, unsigned& m) {
   const f16x2v hh = __builtin_convertvector(f32x2{x0, x1}, f16x2v);   // the FIRST read of x0 / x1 is compiler-visible
   h = __builtin_bit_cast(unsigned, hh);
-  float r0, r1;   // x - xh in one instruction each: f16 operand read straight from the packed pair
+  float r0, r1;   // x - xh (exact in fp32) in one instruction each: f16 operand read straight from the packed pair
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
+  // f16(r * 2^11) straight into the two halves of m (fp32 product, one rounding; the constant rides in an SGPR: VOP3P takes no literal)
+  const float k = kF16ResidualScale;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(m) : "v"(r0), "s"(k));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(m) : "v"(r1), "s"(k));
+}
+
+// The round-2 form of the split, kept for operands whose SCALE is fixed by construction -- the output of a LayerNorm without its
+// affine part (|x| <= sqrt(C), O(1) entries): h = (xh0, xh1), s = h * 2^-11, m = (xm0, xm1) UNSCALED, to go with weights packed
+// with s = 0 as (wh, wm' = (w - wh) * 2^11):  w x ~= wm' * xs + wh * xm + wh * xh at the TRUE scale (no multiply behind the
+// accumulator).  xs and xm are f16 subnormals for |x| < 0.125; the bits that drops are an ABSOLUTE 3e-8 per element, i.e.
+// fp32-grade against a dot product over O(1) entries -- and wrong by 3e-8 / |x| for inputs that are small as a whole, which is
+// why every other operand takes split_f16_pair above.
+__device__ __forceinline__ void split_f16_pair_unit(float x0, float x1, unsigned& h, unsigned& s, unsigned& m) {
+  const f16x2v hh = __builtin_convertvector(f32x2{x0, x1}, f16x2v);
+  h = __builtin_bit_cast(unsigned, hh);
+  float r0, r1;
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
   m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2v));
   s = __builtin_bit_cast(unsigned, hh * f16x2v{(_Float16)0.00048828125f, (_Float16)0.00048828125f});
 }
 
-// D += A*B with A = (wh, wm' [, unused]), B = (xh, xs, xm), smallest terms first
+// max |w| of n floats as the bits of a non-negative float (monotone as unsigned); *out must be zero before the launch.
+// gamma (or null): the maximum of |w[i] * gamma[i % ld]| instead (a LayerNorm's scale folded into the matrix)
+static __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out,
+                                                                 const float* __restrict__ gamma = nullptr, int ld = 1) {
+  unsigned m = 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = gamma ? w[i] * gamma[i % ld] : w[i];
+    const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+    if (b <= 0x7f800000u && b > m) m = b;                      // NaNs do not take part
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = __shfl_xor(m, off);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// 2^s with max |w| 2^s in [8, 16), from the bits absmax_bits_kernel left (1 for a zero, subnormal or infinite maximum);
+// `oscale` = 2^-(11+s), what a consumer multiplies the accumulator of the three f16 products by
+__device__ __forceinline__ float f16x3_weight_scale(unsigned maxbits, float& oscale) {
+  const int e = (int)(maxbits >> 23);                          // biased exponent of the maximum
+  if (e < 16 || e > 250) { oscale = kF16OutputScale; return 1.f; }
+  oscale = __uint_as_float((unsigned)(e - 14) << 23);          // 2^(e - 127 - 3 - 11)
+  return __uint_as_float((unsigned)(257 - e) << 23);           // 2^(3 - (e - 127))
+}
+
+// 1 / p for p a power of two (exact)
+__device__ __forceinline__ float pow2_reciprocal(float p) { return __uint_as_float(0x7f000000u - __float_as_uint(p)); }
+
+// whB = wh * 2^11 of an operand fragment (exact: a power of two, |wh| < 16 by the packers' choice of s)
+__device__ __forceinline__ u32x4 f16x8_times_2048(u32x4 wh) {
+  const _Float16 k1 = (_Float16)2048.0f;
+  const f16x8 k = {k1, k1, k1, k1, k1, k1, k1, k1};
+  return __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, wh) * k);
+}
+
+// D += 2^(11+s) A*B with A = (wh, wm', whB), B = (xh, xm' [, unused]): the two residual products first
 __device__ __forceinline__ f32x4 mfma_f16x3(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
-  c = mfma16x16x32_f16(a[1], b[1], c);
-  c = mfma16x16x32_f16(a[0], b[2], c);
-  c = mfma16x16x32_f16(a[0], b[0], c);
+  c = mfma16x16x32_f16(a[1], b[0], c);
+  c = mfma16x16x32_f16(a[0], b[1], c);
+  c = mfma16x16x32_f16(a[2], b[0], c);
   return c;
 }
 
-// the two forms behind one name (F16 = f16x3, else bf16x6); part order of the B operand: see the two splits
+// the two forms behind one name (F16 = f16x3, else bf16x6); part order of the operand: bf16x6 (h, m, l), f16x3 (xh, xm', 0)
 template <bool F16>
 __device__ __forceinline__ void split_pair_x(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
-  if constexpr (F16) split_f16_pair(x0, x1, p0, p1, p2);
-  else split3_pair(x0, x1, p0, p1, p2);
+  if constexpr (F16) {
+    split_f16_pair(x0, x1, p0, p1);
+    p2 = 0u;
+  } else {
+    split3_pair(x0, x1, p0, p1, p2);
+  }
 }
 template <bool F16>
 __device__ __forceinline__ f32x4 mfma_x(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
@@ -447,12 +514,30 @@ __device__ __forceinline__ f32x4 mfma_x(const u32x4 (&a)[3], const u32x4 (&b)[3]
   else return mfma_bf16x6(a, b, c);
 }
 
-// host: the two f16 parts of a weight (RNE; wm scaled by 2^11, see above)
+// host: s with max |w| 2^s in [8, 16) (0 for an all-zero or non-finite maximum)
+inline int f16x3_weight_shift(float wmax) {
+  if (!(wmax > 0.f) || !std::isfinite(wmax)) return 0;
+  int e;
+  std::frexp(wmax, &e);          // wmax = f 2^e, f in [0.5, 1)
+  return 4 - e;
+}
+
+// host: the two f16 parts of a weight already multiplied by 2^s (RNE; residual scaled by 2^11, see above)
 inline void split2_host_f16(float x, uint16_t& h, uint16_t& m) {
   const _Float16 hh = (_Float16)x;
   const _Float16 mm = (_Float16)((x - (float)hh) * 2048.0f);
   std::memcpy(&h, &hh, 2);
   std::memcpy(&m, &mm, 2);
+}
+
+// host: whB = wh * 2^11 of a leading part produced by split2_host_f16
+inline uint16_t f16_times_2048_host(uint16_t h) {
+  _Float16 hh;
+  std::memcpy(&hh, &h, 2);
+  const _Float16 b = (_Float16)((float)hh * 2048.0f);
+  uint16_t o;
+  std::memcpy(&o, &b, 2);
+  return o;
 }
 
 // host: round-to-nearest-even bf16 split of one float (matches v_cvt_pk_bf16_f32 for finite values)

@@ -290,7 +290,10 @@ __global__ __launch_bounds__(256) void pw_mlp2_kernel(const MlpParams p) {
 template <int CIN_STEPS, bool F16 = false>
 __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const float* s_w1, const float* s_b1,
                                              const u32x4* s_w2, int npair, int lane, const f32x4 (&bias2)[2],
-                                             f32x4 (&acc2)[2][4], int ns = CIN_STEPS, bool cin1 = false) {
+                                             f32x4 (&acc2)[2][4], int ns = CIN_STEPS, bool cin1 = false, float f16_up = 1.f,
+                                             float f16_down = 1.f) {
+  // F16: the three products of a layer-2 term sit at 2^(11+s) times the true scale (common.hpp; s = the shift the host packed
+  // W2 with): the accumulators start from bias2 * f16_up and are multiplied by f16_down = 1 / f16_up when the last unit is in
   const int g = lane >> 4;
   // cin1 (ONE input channel, uniform): layer 1 is w1[c] * x + b1[c] -- 16 plain FMAs per unit instead of four fp32 matrix
   // instructions that would multiply three zero k-slots each (the fp32 MFMA holds the vector lanes for 32 cycles).  Bit-identical:
@@ -309,7 +312,7 @@ __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc2[ot][q] = bias2[ot];
+    for (int q = 0; q < 4; ++q) acc2[ot][q] = F16 ? bias2[ot] * f16_up : bias2[ot];
 
   // Software pipeline over units (tile pair u, pixel-chain pair qp): while the fp32 lanes do layer 1,
   // GELU and the 3-way bf16 split of unit n (-> B operands bg), the bf16 matrix pipe does layer 2 of
@@ -368,8 +371,8 @@ __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const
   // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
   auto unit_mfma = [&](const u32x4(&bg)[2][3], auto qpc, auto slotc) {
     constexpr int qp = decltype(qpc)::value, slot = decltype(slotc)::value;
-    if constexpr (F16) {   // one f16 term per slot: (wm', xs) (wh, xm) (wh, xh)
-      constexpr int PA[3] = {1, 0, 0}, PB[3] = {1, 2, 0};
+    if constexpr (F16) {   // one f16 term per slot, all at one scale: (wm', xh) (wh, xm') (whB, xh)
+      constexpr int PA[3] = {1, 0, 2}, PB[3] = {0, 1, 0};
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -421,6 +424,12 @@ __device__ __forceinline__ void lift_segment(const f32x4 (&xs)[CIN_STEPS], const
   unit_mfma(bg1, I1{}, I1{});
   unit_mfma(bg1, I1{}, I2{});
   (void)nunit;
+  if constexpr (F16) {
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc2[ot][q] *= f16_down;
+  }
 
 }
 
@@ -625,7 +634,8 @@ __global__ __launch_bounds__(256) void pw_proj_small_kernel(const MlpParams p) {
 // partial sum of output co at pixel 4 j + q (to be reduced over the 4 lane groups).
 template <int CO, bool F16 = false>
 __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x4* s_w1, const float* s_b1,
-                                             const float* s_w2, int ntile, int lane, float (&po)[CO][4]) {
+                                             const float* s_w2, int ntile, int lane, float (&po)[CO][4], float f16_down = 1.f) {
+  // F16: s_b1 holds b1 * 2^(11+s) and layer 1 comes out at that scale (common.hpp): one multiply per element in front of the GELU
   const int g = lane >> 4;
 #pragma unroll
   for (int co = 0; co < CO; ++co)
@@ -643,7 +653,7 @@ __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x
   fc1(0, a_cur);
   fc1(ntile > 1 ? 1 : 0, a_nxt);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) g_prev[q] = a_cur[q];
+  for (int q = 0; q < 4; ++q) g_prev[q] = F16 ? a_cur[q] * f16_down : a_cur[q];
   DLWP_GELU8_PROJ(g_prev[0], g_prev[1]);
   DLWP_GELU8_PROJ(g_prev[2], g_prev[3]);
 #pragma unroll
@@ -675,8 +685,8 @@ __device__ __forceinline__ void proj_segment(const u32x4 (&bx)[4][3], const u32x
     for (int i = 0; i < 2; ++i) {
       a_nxt[2 * i] = mfma_x<F16>(wa, bx[2 * i], bb);
       a_nxt[2 * i + 1] = mfma_x<F16>(wa, bx[2 * i + 1], bb);
-      g_new[2 * i] = a_cur[2 * i];
-      g_new[2 * i + 1] = a_cur[2 * i + 1];
+      g_new[2 * i] = F16 ? a_cur[2 * i] * f16_down : a_cur[2 * i];
+      g_new[2 * i + 1] = F16 ? a_cur[2 * i + 1] * f16_down : a_cur[2 * i + 1];
       DLWP_GELU8_PROJ(g_new[2 * i], g_new[2 * i + 1]);
 #pragma unroll
       for (int co = 0; co < CO; ++co)
@@ -1160,6 +1170,11 @@ constexpr bool kDftBf16 = DLWP_TRUNK_DFT_BF16 != 0;
 #ifndef DLWP_PREFETCH_EARLY
 #define DLWP_PREFETCH_EARLY 0   // measured: 1 (the next step's lifting weights requested BEFORE the projection) spills 38 registers
 #endif                          // per lane and loses 8 % (1.501 vs 1.385 ms per rollout); 0 = right before the end-of-step barrier
+// f16x3 products of the trunk's row phase (skip convolution + inverse W-DFT into ONE accumulator, forward W-DFT): the skip
+// weights and the twiddles are packed with the SAME shift s = 3 (twiddles: max |t| = 1 -> [8, 16); skip weights must stay below 2,
+// checked when the plan is made -- a plan with larger ones takes the bf16x6 form), so everything sits at 2^14 times the true scale
+constexpr int kTrunkF16Shift = 3;
+constexpr float kTrunkF16Up = 16384.0f, kTrunkF16Down = 1.0f / 16384.0f;
 constexpr int kSyStride = 528;   // floats per Y row in LDS: 16 k' x 32 c + 16 (bank spread for the P1 B reads)
 
 struct TrunkParams {
@@ -1195,6 +1210,7 @@ struct TrunkParams {
   const float* lift_b1;    // [hid]
   const u32x4* lift_w2b;   // [hid/32][3][2][64]
   const float* lift_b2;    // [32]
+  float lift_up, lift_down, proj_up, proj_down;   // f16x3 form: 2^(11+s) of the lifting W2 / projection W1 images and its inverse
   int proj_hid, proj_co, cout;   // projection width (<= 256), outputs the FMA layer 2 is built for (1, 2, 4), real outputs
   const u32x4* proj_w1b;   // [hid/16][3][64], k order of the resident activation
   const float* proj_b1;    // [hid]
@@ -1374,10 +1390,10 @@ __device__ __forceinline__ void fwd_dft_bf16x6(const float* s_tr, const u32x4* s
         xa[1][i] = mm;
         xa[2][i] = ll;
       }
-      if constexpr (F16) {   // data on the A side: (xs, tm') (xm, th) (xh, th)
-        yacc[ct] = mfma16x16x32_f16(xa[1], tb[1], yacc[ct]);
-        yacc[ct] = mfma16x16x32_f16(xa[2], tb[0], yacc[ct]);
-        yacc[ct] = mfma16x16x32_f16(xa[0], tb[0], yacc[ct]);
+      if constexpr (F16) {   // data on the A side, 2^(11+3) times the true scale (kTrunkF16Down): (xh, tm') (xm', th) (xh, thB)
+        yacc[ct] = mfma16x16x32_f16(xa[0], tb[1], yacc[ct]);
+        yacc[ct] = mfma16x16x32_f16(xa[1], tb[0], yacc[ct]);
+        yacc[ct] = mfma16x16x32_f16(xa[0], tb[2], yacc[ct]);
       } else {
         yacc[ct] = mfma_bf16x6(xa, tb, yacc[ct]);
       }
@@ -1390,6 +1406,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
   extern __shared__ __align__(16) float smem[];
   constexpr int W = 64, KP = 16, C = kC, NT = 64 * ROWS;
   constexpr bool kDftF16 = F16 && (DLWP_F16_DFT != 0);
+  static_assert(!F16 || kDftF16, "f16x3: the skip convolution and the inverse W-DFT share one SCALED accumulator (common.hpp)");
   constexpr bool kDftMx = kDftBf16 || kDftF16;            // W-direction DFTs on the bf16 / f16 matrix instructions
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -1503,7 +1520,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     lds_barrier();
     if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
     f32x4 acc2[2][4];
-    lift_segment<4, F16>(xs, l_w1, l_b1, l_w2, npair, lane, bias2, acc2, p.lift_ns, p.lift_cin1 != 0);
+    lift_segment<4, F16>(xs, l_w1, l_b1, l_w2, npair, lane, bias2, acc2, p.lift_ns, p.lift_cin1 != 0, p.lift_up, p.lift_down);
     if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
@@ -1530,7 +1547,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     wave_lds_fence();
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
-      *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + j * C + 16 * ct + 4 * g) = yacc[ct];
+      *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + j * C + 16 * ct + 4 * g) = kDftF16 ? yacc[ct] * kTrunkF16Down : yacc[ct];
     if (p.trace && tid == p.trace_tid && n_stamp < 64) p.trace[blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
   } else {
 #pragma unroll
@@ -1653,7 +1670,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[ot][q] = bias4[ot];
+      for (int q = 0; q < 4; ++q) acc[ot][q] = F16 ? bias4[ot] * kTrunkF16Up : bias4[ot];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       u32x4 bx[3];
@@ -1868,10 +1885,10 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
         for (int pp = 0; pp < 3; ++pp) tb[pp] = s_tb[(q * 3 + pp) * 64 + lane];
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) {
-          if constexpr (kDftF16) {   // data on the A side: (zs, tm') (zm, th) (zh, th)
-            acc[ot][q] = mfma16x16x32_f16(za[ot][1], tb[1], acc[ot][q]);
-            acc[ot][q] = mfma16x16x32_f16(za[ot][2], tb[0], acc[ot][q]);
-            acc[ot][q] = mfma16x16x32_f16(za[ot][0], tb[0], acc[ot][q]);
+          if constexpr (kDftF16) {   // data on the A side, at the accumulator's scale 2^14: (zh, tm') (zm', th) (zh, thB)
+            acc[ot][q] = mfma16x16x32_f16(za[ot][0], tb[1], acc[ot][q]);
+            acc[ot][q] = mfma16x16x32_f16(za[ot][1], tb[0], acc[ot][q]);
+            acc[ot][q] = mfma16x16x32_f16(za[ot][0], tb[2], acc[ot][q]);
           } else {
             acc[ot][q] = mfma_bf16x6(za[ot], tb, acc[ot][q]);
           }
@@ -1895,7 +1912,10 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vv[ot][r] = f32x4{acc[ot][0][r], acc[ot][1][r], acc[ot][2][r], acc[ot][3][r]};
+      for (int r = 0; r < 4; ++r) {
+        vv[ot][r] = f32x4{acc[ot][0][r], acc[ot][1][r], acc[ot][2][r], acc[ot][3][r]};
+        if constexpr (F16) vv[ot][r] *= kTrunkF16Down;     // skip convolution + inverse DFT + bias, back at the true scale
+      }
     DLWP_STAMP();
     if (l < p.L - 1) {
       // neuralop FNOBlocks.forward_with_postactivation: GELU after every layer but the last
@@ -1926,7 +1946,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
       DLWP_STAMP();
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
-        *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + j * C + 16 * ct + 4 * g) = yacc[ct];
+        *reinterpret_cast<f32x4*>(s_y + wave * kSyStride + j * C + 16 * ct + 4 * g) = kDftF16 ? yacc[ct] * kTrunkF16Down : yacc[ct];
     }
   }
   DLWP_STAMP();
@@ -1976,7 +1996,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
       const int i = tid + k * NT;
       if (i < n_q2) q_w2[i] = pq2[k];
     }
-    if (tid < p.proj_hid) q_b1[tid] = pqb;
+    if (tid < p.proj_hid) q_b1[tid] = F16 ? pqb * p.proj_up : pqb;
     u32x4 bx[4][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -2012,7 +2032,7 @@ __global__ __launch_bounds__(64 * ROWS, 2) void fno_trunk_kernel(const TrunkPara
     auto run = [&](auto coc) {
       constexpr int CO = decltype(coc)::value;
       float po[CO][4];
-      proj_segment<CO, F16>(bx, q_w1, q_b1, q_w2, ntile_p, lane, po);
+      proj_segment<CO, F16>(bx, q_w1, q_b1, q_w2, ntile_p, lane, po, p.proj_down);
 #pragma unroll
       for (int co = 0; co < CO; ++co)
 #pragma unroll
@@ -2160,13 +2180,15 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
               split3_host(kp < KP ? ht[(size_t)kp * W + 4 * jj0 + q] : 0.f, hh[e], mm[e], ll[e]);
             }
             {
-              uint16_t fh[2], fm[2];
+              uint16_t fh[2], fm[2], fb[2];   // (th, tm', thB) of t * 2^kTrunkF16Shift
               for (int e = 0; e < 2; ++e) {
                 const int kp = 8 * gg + 2 * d + e;
-                split2_host_f16(kp < KP ? ht[(size_t)kp * W + 4 * jj0 + q] : 0.f, fh[e], fm[e]);
+                split2_host_f16((kp < KP ? ht[(size_t)kp * W + 4 * jj0 + q] : 0.f) * (float)(1 << kTrunkF16Shift), fh[e], fm[e]);
+                fb[e] = f16_times_2048_host(fh[e]);
               }
               htbh[(((size_t)q * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)fh[0] | ((uint32_t)fh[1] << 16);
               htbh[(((size_t)q * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)fm[0] | ((uint32_t)fm[1] << 16);
+              htbh[(((size_t)q * 3 + 2) * 64 + l) * 4 + d] = (uint32_t)fb[0] | ((uint32_t)fb[1] << 16);
             }
             htb[(((size_t)q * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
             htb[(((size_t)q * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16);
@@ -2179,13 +2201,15 @@ struct SpectralCore {  // what one spectral convolution stage needs on the devic
               split3_host(htt[(size_t)w * KP + jj0], hh[e], mm[e], ll[e]);
             }
             {
-              uint16_t fh[2], fm[2];
+              uint16_t fh[2], fm[2], fb[2];
               for (int e = 0; e < 2; ++e) {
                 const int w = 32 * kb + 8 * gg + 2 * d + e;
-                split2_host_f16(htt[(size_t)w * KP + jj0], fh[e], fm[e]);
+                split2_host_f16(htt[(size_t)w * KP + jj0] * (float)(1 << kTrunkF16Shift), fh[e], fm[e]);
+                fb[e] = f16_times_2048_host(fh[e]);
               }
               httbh[(((size_t)kb * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)fh[0] | ((uint32_t)fh[1] << 16);
               httbh[(((size_t)kb * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)fm[0] | ((uint32_t)fm[1] << 16);
+              httbh[(((size_t)kb * 3 + 2) * 64 + l) * 4 + d] = (uint32_t)fb[0] | ((uint32_t)fb[1] << 16);
             }
             httb[(((size_t)kb * 3 + 0) * 64 + l) * 4 + d] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
             httb[(((size_t)kb * 3 + 1) * 64 + l) * 4 + d] = (uint32_t)mm[0] | ((uint32_t)mm[1] << 16);
@@ -2350,6 +2374,7 @@ struct dlwp_fno2d_plan {
   SpectralCore sc;
   DevBuf lift_w1p, lift_b1, lift_w2p, lift_b2, lift_w2b;
   DevBuf lift_w2h, proj_w1hp;      // f16x3 operands of the fused step kernel (precision_form 2)
+  int lift_shift = 0, proj_shift = 0;   // the shift s those two matrices were packed with (common.hpp f16x3_weight_shift)
   std::vector<DevBuf> wshp;        // likewise the skip weights, trunk k order
   DevBuf proj_w1p, proj_b1, proj_w2p, proj_b2, proj_w2v, proj_w1b, proj_w1bp;   // w1bp: k order of the trunk's resident activation
   int proj_co = 0;  // outputs handled by pw_proj_small_kernel (1, 2 or 4), 0 = generic MFMA path
@@ -2366,8 +2391,8 @@ static void pack_w1(std::vector<float>& dst, const float* w1, int hid, int cin, 
       }
 }
 // bf16x6 A operands of a [rows][K = 32] matrix block: [rows/16][3 parts][64 lanes][4 dwords]
-// f16: the same layout holding the f16x3 parts (wh, wm' = (w - wh) * 2^11, 0) -- common.hpp
-static void pack_a_bf16x3(std::vector<uint32_t>& dst, const float* w, int rows, int ld, bool f16 = false) {
+// f16: the same layout holding the f16x3 parts (wh = f16(w 2^s), wm' = (w 2^s - wh) * 2^11, whB = wh * 2^11) -- common.hpp
+static void pack_a_bf16x3(std::vector<uint32_t>& dst, const float* w, int rows, int ld, bool f16 = false, float f16_scale = 1.f) {
   dst.assign((size_t)(rows / 16) * 3 * 64 * 4, 0u);
   for (int t = 0; t < rows / 16; ++t)
     for (int l = 0; l < 64; ++l)
@@ -2375,8 +2400,10 @@ static void pack_a_bf16x3(std::vector<uint32_t>& dst, const float* w, int rows, 
         uint16_t h[2], m[2], lo[2] = {0, 0};
         for (int e = 0; e < 2; ++e) {
           const float v = w[(size_t)(16 * t + (l & 15)) * ld + 8 * (l >> 4) + 2 * d + e];
-          if (f16) split2_host_f16(v, h[e], m[e]);
-          else split3_host(v, h[e], m[e], lo[e]);
+          if (f16) {
+            split2_host_f16(v * f16_scale, h[e], m[e]);
+            lo[e] = f16_times_2048_host(h[e]);
+          } else split3_host(v, h[e], m[e], lo[e]);
         }
         const size_t base = ((size_t)t * 3 * 64 + l) * 4 + d;
         dst[base + 0 * 64 * 4] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
@@ -2387,7 +2414,7 @@ static void pack_a_bf16x3(std::vector<uint32_t>& dst, const float* w, int rows, 
 
 // bf16x6 A operands of layer 2 of the lifting MLP: W2 [32][hid] -> [hid/32][3 parts][2 out tiles][64 lanes][4 dwords];
 // k-slot (g, jj) of tile pair u is hidden channel 16*(2u + jj/4) + 4g + jj%4 (accumulator order of layer 1)
-static void pack_lift_w2_bf16x3(std::vector<uint32_t>& dst, const float* w2, int hid, bool f16 = false) {
+static void pack_lift_w2_bf16x3(std::vector<uint32_t>& dst, const float* w2, int hid, bool f16 = false, float f16_scale = 1.f) {
   const int npair = hid / 32;
   dst.assign((size_t)npair * 3 * 2 * 64 * 4, 0u);
   for (int u = 0; u < npair; ++u)
@@ -2399,8 +2426,10 @@ static void pack_lift_w2_bf16x3(std::vector<uint32_t>& dst, const float* w2, int
             const int jj = 2 * d + e, g = l >> 4;
             const int ch = 16 * (2 * u + jj / 4) + 4 * g + jj % 4;
             const float v = w2[(size_t)(16 * ot + (l & 15)) * hid + ch];
-            if (f16) split2_host_f16(v, h[e], m[e]);
-            else split3_host(v, h[e], m[e], lo[e]);
+            if (f16) {
+              split2_host_f16(v * f16_scale, h[e], m[e]);
+              lo[e] = f16_times_2048_host(h[e]);
+            } else split3_host(v, h[e], m[e], lo[e]);
           }
           auto at = [&](int part) -> uint32_t& { return dst[((((size_t)u * 3 + part) * 2 + ot) * 64 + l) * 4 + d]; };
           at(0) = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
@@ -2472,6 +2501,19 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
   p->cin = d->in_channels; p->hid_l = d->lifting_channels; p->hid_p = d->projection_channels;
   p->cout = d->out_channels; p->L = d->n_layers; p->H = d->height; p->W = d->width;
   p->cin_steps = (p->cin + 3) / 4;
+  if (p->k.f16x3) {
+    // f16x3 (common.hpp): every weight image is packed as w * 2^s with max |w| 2^s in [8, 16) so that neither part of any weight
+    // is an f16 subnormal and whB = wh * 2^11 cannot overflow.  Lifting W2 and projection W1 have accumulators of their own and
+    // take their own s; the skip weights share an accumulator with the inverse W-DFT, whose twiddles are packed with s = 3:
+    // skip weights of 2 or more (never seen; the init is 1 / sqrt(32)) send the plan to the bf16x6 form.
+    auto amax = [](const float* w, size_t n) { float m = 0.f; for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i])); return m; };
+    p->lift_shift = f16x3_weight_shift(amax(d->lift_w2, (size_t)kC * p->hid_l));
+    p->proj_shift = f16x3_weight_shift(amax(d->proj_w1, (size_t)p->hid_p * kC));
+    float skip_max = 0.f;
+    for (int l = 0; l < p->L; ++l) skip_max = std::fmax(skip_max, amax(d->skip_w[l], (size_t)kC * kC));
+    const bool ok = std::isfinite(skip_max) && skip_max < 2.0f && std::abs(p->lift_shift) <= 40 && std::abs(p->proj_shift) <= 40;
+    if (!ok) p->k.f16x3 = false;
+  }
   int32_t rc = p->sc.build(d->height, d->width, d->n_rows, d->n_cols, d->rows_in, d->rows_out, d->fwd_scale,
                            d->inv_scale, s);
   if (rc != DLWP_OK) { delete p; return rc; }
@@ -2493,7 +2535,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
       if ((e = p->lift_w2b.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
       if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
       if (p->k.f16x3) {
-        pack_lift_w2_bf16x3(wb, d->lift_w2, p->hid_l, true);
+        pack_lift_w2_bf16x3(wb, d->lift_w2, p->hid_l, true, std::ldexp(1.f, p->lift_shift));
         if ((e = p->lift_w2h.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
       }
@@ -2530,7 +2572,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
         if ((e = p->proj_w1bp.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
         if (p->k.f16x3) {
-          pack_a_bf16x3(wb, wperm.data(), p->hid_p, kC, true);
+          pack_a_bf16x3(wb, wperm.data(), p->hid_p, kC, true, std::ldexp(1.f, p->proj_shift));
           if ((e = p->proj_w1hp.upload(wb.data(), wb.size() * 4, s)) != hipSuccess) break;
           if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
         }
@@ -2568,7 +2610,7 @@ extern "C" int32_t dlwp_fno2d_plan_create(dlwp_fno2d_plan** out, const dlwp_fno2
         if ((e = p->wsbp[l].upload(wsbp.data(), wsbp.size() * 4, s)) != hipSuccess) break;
         if (p->k.f16x3) {
           if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
-          pack_a_bf16x3(wsbp, wperm.data(), kC, kC, true);
+          pack_a_bf16x3(wsbp, wperm.data(), kC, kC, true, (float)(1 << kTrunkF16Shift));
           if ((e = p->wshp[l].upload(wsbp.data(), wsbp.size() * 4, s)) != hipSuccess) break;
         }
       }
@@ -2863,7 +2905,10 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
                         p->cin == io->n_prog && p->k.feed_regs) ? 1 : 0;
       }
       const bool f16 = p->k.f16x3 && p->lift_w2h.p && p->proj_w1hp.p && !io->lift_only;
+      tp.lift_up = tp.lift_down = tp.proj_up = tp.proj_down = 1.f;
       if (f16) {   // f16x3 operands (the unfused kernels and the plain trunk keep bf16x6)
+        tp.lift_up = std::ldexp(1.f, 11 + p->lift_shift); tp.lift_down = std::ldexp(1.f, -(11 + p->lift_shift));
+        tp.proj_up = std::ldexp(1.f, 11 + p->proj_shift); tp.proj_down = std::ldexp(1.f, -(11 + p->proj_shift));
         tp.lift_w2b = p->lift_w2h.as<u32x4>();
         tp.proj_w1b = p->proj_w1hp.as<u32x4>();
         tp.tb = p->sc.tbh.as<u32x4>(); tp.ttb = p->sc.ttbh.as<u32x4>();

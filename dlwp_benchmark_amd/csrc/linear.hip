@@ -47,6 +47,7 @@ struct Params {
   float* out;                  // [M][N]
   long long M, wpart;          // wpart: elements between two parts of w
   int N, K, act;
+  const float* wscale;         // f16x3 form: {bits of max |w|, 2^-(11+s)} written by the packer behind the two images; else null
 };
 
 // Output stores as inline asm: hipcc guards the reuse of a store's data registers with s_waitcnt vmcnt -- and knowing
@@ -67,8 +68,9 @@ struct Cursor {          // one (tile, k-step) position of this workgroup's flat
   int slab, nt, ks, left;    // slab index inside the XCD, n-tile, k-step, tiles after this one
 };
 
-// F16 (dlwp_linear_f16x3, NP = 3): the "f16x3" form of common.hpp -- x parts (xh, xh * 2^-11, xm), W parts (wh, wm' = (w - wh) * 2^11),
-// three f16 products per output instead of six bf16 ones, 5 instead of 11 split slots per pair; only TWO W images are staged.
+// F16 (dlwp_linear_f16x3, NP = 3): the "f16x3" form of common.hpp -- x parts (xh, xm' = (x - xh) * 2^11), W parts (wh, wm' = (w 2^s - wh) * 2^11;
+// whB = wh * 2^11 is formed in registers), three f16 products per output instead of six bf16 ones, 5 instead of 11 split slots per
+// pair; only TWO W images are staged.  The accumulator holds 2^(11+s) times the result: the epilogue's bias add is an FMA.
 // XB16 / OB16 (bf16-operand form only): x is ALREADY bf16 [M][K] / the output is stored as bf16 [M][N].  The MLP of a block
 // in the bf16 form hands its hidden activation from fc1 to fc2 this way: fc2 rounds its input to bf16 anyway, so the
 // result is bit-identical and the widest tensor of the block crosses HBM at half the bytes in both directions.
@@ -78,8 +80,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   constexpr int XQ = XB16 ? 2 : 4;                   // 16-byte x loads per thread and k-step
   constexpr int TN = BN / 32;                        // 16-row W tiles per wave (wave tile: 64 m x BN/2 n)
   constexpr int NPW = F16 ? 2 : NP;                  // W parts staged per k-step
-  constexpr int NPX = F16 ? 2 : NP;                  // x images in LDS (f16x3: xh and xm; xs = xh * 2^-11 is formed in registers --
-                                                     // the kernel is bound by LDS read bandwidth, ~430 bytes per matrix instruction)
+  constexpr int NPX = F16 ? 2 : NP;                  // x images in LDS (f16x3: xh and xm')
   constexpr int XBYTES = NPX * 8192;                 // x tile: NPX parts x 128 rows x 64 bytes
   constexpr int WPART = BN * 64, WSTAGE = NPW * WPART;
   constexpr int CH = NPW * BN * 4;                   // 16-byte chunks per W stage
@@ -90,6 +91,8 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
+  float osc = 1.f;
+  if constexpr (F16) osc = p.wscale[1];
 
   // this workgroup's tiles: XCD x (= blockIdx % 8) owns the 128-row slabs x, x + 8, ...; its workgroups walk the
   // (slab, n-tile) pairs n-tile fastest, so the workgroups that run together on an XCD share slabs of x in its L2
@@ -191,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
         split_pair_x<F16>(src[q][0], src[q][1], h0, m0_, l0);
         split_pair_x<F16>(src[q][2], src[q][3], h1, m1, l1);
         *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
-        if constexpr (F16) {   // split order (xh, xs, xm): xm is the second image, xs is not stored
-          *reinterpret_cast<uint2*>(d + 8192) = uint2{l0, l1};
+        if constexpr (F16) {   // split order (xh, xm', -)
+          *reinterpret_cast<uint2*>(d + 8192) = uint2{m0_, m1};
         } else {
           *reinterpret_cast<uint2*>(d + 8192) = uint2{m0_, m1};
           *reinterpret_cast<uint2*>(d + 16384) = uint2{l0, l1};
@@ -269,7 +272,17 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
       const long long m_u = mbase + 16 * a, m_v = m_u + 16;
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
-        f32x4 u = acc[a][b] + bv[b], v = acc[a + 1][b] + bv[b];
+        f32x4 u, v;
+        if constexpr (F16) {   // the accumulator holds 2^(11+s) times the product sum
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            u[e] = __builtin_fmaf(acc[a][b][e], osc, bv[b][e]);
+            v[e] = __builtin_fmaf(acc[a + 1][b][e], osc, bv[b][e]);
+          }
+        } else {
+          u = acc[a][b] + bv[b];
+          v = acc[a + 1][b] + bv[b];
+        }
         if (p.act) gelu_erf8_fma(u, v);
         if constexpr (RES) {
           u += rs[a][b];
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
     for (int a = 0; a < 4; ++a) {
       if constexpr (F16) {
         xb[a][0] = *reinterpret_cast<const u32x4*>(xfrag + a * 1024);
-        xb[a][2] = *reinterpret_cast<const u32x4*>(xfrag + 8192 + a * 1024);
+        xb[a][1] = *reinterpret_cast<const u32x4*>(xfrag + 8192 + a * 1024);
       } else {
 #pragma unroll
         for (int part = 0; part < NP; ++part) xb[a][part] = *reinterpret_cast<const u32x4*>(xfrag + part * 8192 + a * 1024);
@@ -318,12 +331,6 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
     asm volatile("" ::: "memory");
     // x(t+1) has landed when at most this step's G loads of W are outstanding
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]), "+v"(px[3]) : "n"(G));
-    if constexpr (F16) {                     // xs = xh * 2^-11 (exact unless |x| < 0.125): 16 packed multiplies instead of 4 KB of LDS reads
-      const _Float16 k1 = (_Float16)0.00048828125f;
-      const f16x8 k = {k1, k1, k1, k1, k1, k1, k1, k1};
-#pragma unroll
-      for (int a = 0; a < 4; ++a) xb[a][1] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, xb[a][0]) * k);
-    }
     x_store(px);
     if (advance(cx)) x_rows(cx);
     x_issue(px, cx);                         // x(t+2), into the registers just split
@@ -335,12 +342,15 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
         for (int part = 0; part < NPW; ++part) wa[part] = *reinterpret_cast<const u32x4*>(wf + part * WPART + b * 1024);
       }
       if constexpr (F16) {
-        // three products, smallest first: (A part, B part) = (wm', xs) (wh, xm) (wh, xh)
-        constexpr int PA[3] = {1, 0, 0}, PB[3] = {1, 2, 0};
+        // three products at one scale, the residual ones first: (A part, B part) = (wm', xh) (wh, xm') (whB, xh); whB = wh * 2^11
+        // is four packed multiplies per W fragment (it replaces the xs = xh * 2^-11 of round 2: the same count at TN = 4)
+        const u32x4 whb = f16x8_times_2048(wa[0]);
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_f16(wa[1], xb[a][0], acc[a][b]);
 #pragma unroll
-          for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_f16(wa[PA[term]], xb[a][PB[term]], acc[a][b]);
+        for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_f16(wa[0], xb[a][1], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_f16(whb, xb[a][0], acc[a][b]);
       } else if constexpr (NP == 3) {
         // six cross products, smallest first: (A part, B part) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); A = W, B = x
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -368,13 +378,18 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the prefetches issued past the end
 }
 
-// weights [N][K] fp32 -> the two f16 images [N][K] of the f16x3 form (wh, wm' = (w - wh) * 2^11)
+// weights [N][K] fp32 -> the two f16 images [N][K] of the f16x3 form (wh = f16(w 2^s), wm' = (w 2^s - wh) * 2^11); scale[0] holds the
+// bits of max |w|, scale[1] receives 2^-(11+s)
 __global__ __launch_bounds__(256) void linear_pack_f16_kernel(const float* __restrict__ w, unsigned short* __restrict__ h,
-                                                              unsigned short* __restrict__ m, long long pairs) {
+                                                              unsigned short* __restrict__ m, long long pairs, float* __restrict__ scale) {
+  float osc;
+  const float ws = f16x3_weight_scale(reinterpret_cast<const unsigned*>(scale)[0], osc);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale[1] = osc;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (long long)gridDim.x * 256) {
     const float2 v = reinterpret_cast<const float2*>(w)[i];
-    const f16x2v hh = __builtin_convertvector(f32x2{v.x, v.y}, f16x2v);
-    const f32x2 r = {(v.x - (float)hh[0]) * 2048.0f, (v.y - (float)hh[1]) * 2048.0f};
+    const float a = v.x * ws, b = v.y * ws;                    // exact (a power of two)
+    const f16x2v hh = __builtin_convertvector(f32x2{a, b}, f16x2v);
+    const f32x2 r = {(a - (float)hh[0]) * 2048.0f, (b - (float)hh[1]) * 2048.0f};
     reinterpret_cast<unsigned*>(h)[i] = __builtin_bit_cast(unsigned, hh);
     reinterpret_cast<unsigned*>(m)[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
   }
@@ -471,13 +486,18 @@ extern "C" int32_t dlwp_linear_pack_f16x3(const float* weight_dev, int32_t out_f
   const size_t bytes = dlwp_linear_packed_bytes(out_features, in_features);
   DLWP_REQUIRE(bytes > 0, DLWP_ERR_UNSUPPORTED, "linear: in_features %d must be a multiple of 32, out_features %d of 4",
                in_features, out_features);
-  const size_t part = bytes / 3;      // same buffer size as the bf16 images; the third part stays unused
+  const size_t part = bytes / 3;      // same buffer size as the bf16 images; the third part holds {bits of max |w|, 2^-(11+s)}
   char* b = reinterpret_cast<char*>(packed_dev);
   const long long pairs = (long long)out_features * in_features / 2;
   long long blocks = (pairs + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(lin::linear_pack_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     weight_dev, reinterpret_cast<unsigned short*>(b), reinterpret_cast<unsigned short*>(b + part), pairs);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* scale = reinterpret_cast<float*>(b + 2 * part);
+  DLWP_HIP_CHECK(hipMemsetAsync(scale, 0, 8, st));
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight_dev, 2 * pairs,
+                     reinterpret_cast<unsigned*>(scale), (const float*)nullptr, 1);
+  hipLaunchKernelGGL(lin::linear_pack_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                     weight_dev, reinterpret_cast<unsigned short*>(b), reinterpret_cast<unsigned short*>(b + part), pairs, scale);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
@@ -500,6 +520,7 @@ static int32_t linear_run(int form, const float* x_dev, const void* packed_dev, 
   p.wpart = (long long)(part / 2);
   p.x = x_dev; p.bias = bias_dev; p.resid = resid_dev; p.out = out_dev;
   p.M = rows; p.N = out_features; p.K = in_features; p.act = act;
+  p.wscale = form == 2 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed_dev) + 2 * part) : nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return lin::launch(p, form, s);
 }

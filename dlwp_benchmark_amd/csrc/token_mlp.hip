@@ -63,7 +63,15 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
   unsigned* w1l = w2hm + n_w2hm(hid, OT) * 4;
   unsigned* w2l = w1l + n_w1l(hid, KS) * 4;
   const int n1 = (hid / 16) * KS * 64 * 4, n2 = (hid / 32) * OT * 64 * 4;
-  // f16: the "f16x3" images (common.hpp) -- h = f16(w), m = f16((w - h) * 2^11), no third part
+  // f16: the "f16x3" images (common.hpp) -- h = f16(w 2^s), m = f16((w 2^s - h) * 2^11), no third part.  W1 (its input is a
+  // LayerNorm's output: the unit-scale form, split_f16_pair_unit) keeps s = 0; W2 takes the s of its maximum, found by
+  // absmax_bits_kernel into scale[0] (the start of the unused w1l region), and scale[1] receives 2^-(11+s)
+  float ws2 = 1.f;
+  if (f16) {
+    float osc;
+    ws2 = f16x3_weight_scale(reinterpret_cast<const unsigned*>(w1l)[0], osc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(w1l)[1] = osc;
+  }
   auto split = [&](float a, float b, unsigned& h, unsigned& m, unsigned& lo) {
     if (f16) {
       const f16x2v hh = __builtin_convertvector(f32x2{a, b}, f16x2v);
@@ -89,14 +97,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
       split(gamma ? src[0] * gamma[ch] : src[0], gamma ? src[1] * gamma[ch + 1] : src[1], h, m, lo);
       w1hm[((size_t)(tk * 2 + 0) * 64 + l) * 4 + d] = h;
       w1hm[((size_t)(tk * 2 + 1) * 64 + l) * 4 + d] = m;
-      w1l[((size_t)tk * 64 + l) * 4 + d] = lo;
+      if (!f16) w1l[((size_t)tk * 64 + l) * 4 + d] = lo;
     } else {
       const int k = i - n1;
       const int d = k & 3, l = (k >> 2) & 63, uo = k >> 8;   // uo = u * OT + ot
       const int u = uo / OT, ot = uo % OT, g = l >> 4, jj = 2 * d;
       const int ch = 16 * (2 * u + jj / 4) + 4 * g + jj % 4;
       const float* src = w2 + (size_t)(16 * ot + (l & 15)) * hid + ch;
-      split(src[0], src[1], h, m, lo);
+      split(src[0] * ws2, src[1] * ws2, h, m, lo);
       w2hm[((size_t)((u * 2 + 0) * OT + ot) * 64 + l) * 4 + d] = h;
       w2hm[((size_t)((u * 2 + 1) * OT + ot) * 64 + l) * 4 + d] = m;
       w2l[((size_t)uo * 64 + l) * 4 + d] = lo;
@@ -116,8 +124,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w1,
 __device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
 
-// F16: the f16x3 product form (common.hpp) -- B operands (xh, xh * 2^-11, xm), A operands the two LDS-resident images
-// (wh, wm'), three products per accumulator; the third weight image and its global loads do not exist.
+// F16: the f16x3 product form (common.hpp), A operands the two LDS-resident images (wh, wm'), three products per accumulator;
+// the third weight image and its global loads do not exist.  Layer 1 (input = a LayerNorm's output, O(1) by construction) in
+// the unit-scale form: B operands (xh, xh * 2^-11, xm), true-scale accumulator.  Layer 2 (input = GELU(fc1), as small as fc1's
+// weights make it) in the scaled form: B operands (xh, xm'), whB = wh * 2^11 formed from the wh fragment, accumulator at
+// 2^(11+s) times the true scale -- it starts from (residual + bias) * 2^(11+s) and is multiplied back once per pass.
 __device__ constexpr int kPA16[3] = {1, 0, 0};
 __device__ constexpr int kPB16[3] = {1, 2, 0};
 
@@ -173,6 +184,11 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
   // 256 VGPRs with spills and none in the MERGE + NEXT variant)
   // (g_op: an OPAQUE copy of g, refreshed every pass -- otherwise hipcc hoists these pass-invariant LDS reads out of the
   // pass loop and keeps their 16 + 32 registers live across the whole kernel)
+  float up2 = 1.f, down2 = 1.f;     // f16x3, layer 2: 2^(11+s) of the packed W2 and its inverse
+  if constexpr (F16) {
+    down2 = reinterpret_cast<const float*>(p.w1l)[1];
+    up2 = pow2_reciprocal(down2);
+  }
   int g_op = g;
   auto b2v = [&](int ot) { return *reinterpret_cast<const f32x4*>(s_b2 + 16 * ot + 4 * g_op); };
 
@@ -248,6 +264,10 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
         const f32x4 bias2 = b2v(ot);
         acc2[ot][0] = svq[0][ot] + bias2;
         acc2[ot][1] = svq[1][ot] + bias2;
+        if constexpr (F16) {
+          acc2[ot][0] *= up2;
+          acc2[ot][1] *= up2;
+        }
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -274,7 +294,8 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {   // k-slots 2i, 2i+1 of k-step ks = channels 16 (2 ks + i / 2) + 4 g + 2 (i % 2), + 1
             unsigned hh, mm, ll;
-            split_pair_x<F16>(sv[2 * ks + i / 2][2 * (i % 2)] * rstd, sv[2 * ks + i / 2][2 * (i % 2) + 1] * rstd, hh, mm, ll);
+            if constexpr (F16) split_f16_pair_unit(sv[2 * ks + i / 2][2 * (i % 2)] * rstd, sv[2 * ks + i / 2][2 * (i % 2) + 1] * rstd, hh, mm, ll);
+            else split_pair_x<false>(sv[2 * ks + i / 2][2 * (i % 2)] * rstd, sv[2 * ks + i / 2][2 * (i % 2) + 1] * rstd, hh, mm, ll);
             bx[q][ks][0][i] = hh;
             bx[q][ks][1][i] = mm;
             bx[q][ks][2][i] = ll;
@@ -324,7 +345,8 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             unsigned hh, mm, ll;
-            split_pair_x<F16>(v[ks][i / 2][2 * (i % 2)], v[ks][i / 2][2 * (i % 2) + 1], hh, mm, ll);
+            static_assert(!F16 || MERGE, "f16x3: layer 1 uses the unit-scale split, which needs the LayerNorm of the MERGE variant in front");
+            split_pair_x<false>(v[ks][i / 2][2 * (i % 2)], v[ks][i / 2][2 * (i % 2) + 1], hh, mm, ll);
             bx[q][ks][0][i] = hh;
             bx[q][ks][1][i] = mm;
             bx[q][ks][2][i] = ll;
@@ -409,14 +431,17 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
           wb[oo][1] = s_w2[((u * 2 + 1) * OT + oh + oo) * 64 + lane];
           if constexpr (!F16) wb[oo][2] = wl2[oh + oo];
         }
-        if constexpr (F16) {
+        if constexpr (F16) {   // (wm', xh) (wh, xm') (whB, xh), all at 2^(11+s)
+#pragma unroll
+          for (int oo = 0; oo < 2; ++oo) wb[oo][2] = f16x8_times_2048(wb[oo][0]);
+          constexpr int PA2[3] = {1, 0, 2}, PB2[3] = {0, 1, 0};
 #pragma unroll
           for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int oo = 0; oo < 2; ++oo)
 #pragma unroll
               for (int q = 0; q < 2; ++q)
-                acc2[oh + oo][q] = mfma16x16x32_f16(wb[oo][kPA16[term]], bg[q][kPB16[term]], acc2[oh + oo][q]);
+                acc2[oh + oo][q] = mfma16x16x32_f16(wb[oo][PA2[term]], bg[q][PB2[term]], acc2[oh + oo][q]);
         } else {
 #pragma unroll
         for (int term = 0; term < 6; ++term)
@@ -435,6 +460,12 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(const Params p) {
     for (int u = 0; u < npair; ++u) {
       unit(u);
       stamp();
+    }
+    if constexpr (F16) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc2[ot][q] *= down2;
     }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
@@ -509,6 +540,13 @@ static int32_t token_mlp_pack(const float* w1_dev, const float* w2_dev, const fl
                "LayerNorm weight and bias must be given together");
   DLWP_REQUIRE(token_mlp_shape_ok(channels, hidden, nullptr), DLWP_ERR_UNSUPPORTED,
                "token MLP: channels %d (64 supported), hidden %d (multiple of 64, <= 256: weights must fit LDS)", channels, hidden);
+  if (f16) {   // the shift of W2's f16 images: max |w2| -> scale[0] at the start of the (unused) w1l region
+    const int KS = channels / 32, OT = channels / 16;
+    unsigned* scale = reinterpret_cast<unsigned*>(packed_dev) + (tmlp::n_w1hm(hidden, KS) + tmlp::n_w2hm(hidden, OT)) * 4;
+    DLWP_HIP_CHECK(hipMemsetAsync(scale, 0, 8, reinterpret_cast<hipStream_t>(stream)));
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w2_dev,
+                       (long long)channels * hidden, scale, (const float*)nullptr, 1);
+  }
   hipLaunchKernelGGL(tmlp::pack_kernel, dim3(64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w1_dev, w2_dev,
                      ln_gamma_dev, ln_beta_dev, b1_dev, reinterpret_cast<unsigned*>(packed_dev), channels, hidden, merged_layout ? 1 : 0,
                      f16);

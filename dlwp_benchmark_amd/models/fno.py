@@ -237,7 +237,7 @@ class FNO2DModule(HipBackbone):
                self._debug_spin_limit, self.check)
         if self._plan is not None and key == self._plan_key:
             return self._plan
-        if self._plan is not None and self.check == "deferred":
+        if self._plan is not None and getattr(self, "_plan_check", None) == "deferred":
             # the sticky failure counters live in the plan: launches of the OLD plan that have not been verified yet are
             # verified now (raises DLWP_ERR_TIMEOUT / DLWP_ERR_RANGE here), before a rebuild would drop them
             self.verify()
@@ -297,7 +297,7 @@ class FNO2DModule(HipBackbone):
         with torch.cuda.device(device):
             _lib.check(lib.dlwp_fno2d_plan_create(ctypes.byref(plan), ctypes.byref(d), _lib.stream_ptr()),
                        "dlwp_fno2d_plan_create")
-        self._plan, self._plan_key = plan, key
+        self._plan, self._plan_key, self._plan_check = plan, key, self.check
         return plan
 
     # ------------------------------------------------------------------ compute
