@@ -121,11 +121,13 @@ class _EarthSpecificBlock(nn.Module):
         if not x.is_contiguous() or (self.training and torch.is_grad_enabled()):   # (training: no in-place residual form)
             if pend is not None:
                 x = x + pend
-            qkv = self.attn.qkv(self.norm1(x))
+            # (training: the four Linears and the attention run their HIP kernels forward AND backward -- ops.linear_any ->
+            # training._LinearFn, ops.window_attention -> training._WindowAttentionFn; GELU / LayerNorm / adds are torch operators)
+            qkv = ops.linear_any(self.norm1(x), self.attn.qkv)
             a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec,
                                      precision=self.attention_precision)
-            x = x + self.attn.proj(a)
-            return x + self.mlp(self.norm2(x)), None
+            x = x + ops.linear_any(a, self.attn.proj)
+            return x + ops.linear_any(ops.linear_any(self.norm2(x), self.mlp.fc1, act=1), self.mlp.fc2), None
         if self.linear_form != "rocblas" and ops.attention_block_linears_supported(self.dim, self.mlp.fc1.out_features):
             # the four Linears as dlwp_linear_f32 (fp32-accurate GEMM on the bf16 pipe) or dlwp_linear_bf16, bias / GELU /
             # residual adds in their epilogues, in place on x

@@ -91,6 +91,38 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table:
     return out
 
 
+def window_attention_backward(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table: torch.Tensor, spec: WindowSpec,
+                              grad_out: torch.Tensor):
+    """Gradients of window_attention (fp32) with respect to qkv, the qkv bias (through zero-padded tokens; None when the
+    descriptor does not pad or no bias was given) and the bias table: dlwp_window_attn_bwd_f32, flash-style -- the scores are
+    recomputed per tile, no [B, heads, N, N] tensor exists (reference backward: scripts/train.py:271 through
+    swin_transformer.py:122-154 / panguweather.py:176-211)."""
+    _lib.require_cuda_tensor(qkv, "qkv")
+    _lib.require_cuda_tensor(table, "bias table")
+    _lib.require_cuda_tensor(qkv_bias, "qkv bias")
+    _lib.require_cuda_tensor(grad_out, "grad_out")
+    qkv, table, grad_out = qkv.contiguous(), table.contiguous(), grad_out.contiguous()
+    b, l, c3 = qkv.shape
+    c = spec.heads * spec.head_dim
+    if c3 != 3 * c or l != spec.grid[0] * spec.grid[1] * spec.grid[2] or tuple(grad_out.shape) != (b, l, c):
+        raise _lib.DlwpError(f"qkv {tuple(qkv.shape)} / grad_out {tuple(grad_out.shape)} do not match grid {tuple(spec.grid)} x 3*{c}")
+    padded = tuple(spec.padded) != tuple(spec.grid)
+    gqkv = torch.empty_like(qkv)
+    gtab = torch.empty_like(table)
+    gbias = torch.empty(3 * c, device=qkv.device, dtype=torch.float32) if (padded and qkv_bias is not None) else None
+    lib = _lib.load()
+    d = spec.to_c()
+    with torch.cuda.device(qkv.device):
+        nbytes = int(lib.dlwp_window_attn_bwd_workspace_bytes(ctypes.byref(d), b))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        _lib.check(lib.dlwp_window_attn_bwd_f32(ctypes.byref(d), qkv.data_ptr(),
+                                                qkv_bias.contiguous().data_ptr() if qkv_bias is not None else None,
+                                                table.data_ptr(), grad_out.data_ptr(), gqkv.data_ptr(),
+                                                gbias.data_ptr() if gbias is not None else None, gtab.data_ptr(), b,
+                                                ws.data_ptr(), nbytes, _lib.stream_ptr()), "dlwp_window_attn_bwd_f32")
+    return gqkv, gbias, gtab
+
+
 ACTS = {"none": 0, "gelu": 1, "tanh": 2, "relu": 3, "silu": 4}
 
 
@@ -716,6 +748,29 @@ class LinearWeights:
         return self._buf
 
 
+def linear_raw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """x [..., K] @ weight[N, K]^T + bias through dlwp_linear_f32 (fp32-accurate) for a weight that is a plain tensor -- the
+    three GEMMs of a Linear's training step (training._LinearFn); the weight is split on the device per call."""
+    _lib.require_cuda_tensor(x, "x")
+    _lib.require_cuda_tensor(weight, "weight")
+    _lib.require_cuda_tensor(bias, "bias")
+    x, weight = x.contiguous(), weight.contiguous()
+    n, k = weight.shape
+    if x.shape[-1] != k:
+        raise _lib.DlwpError(f"linear: input width {x.shape[-1]} does not match in_features {k}")
+    lib = _lib.load()
+    nbytes = int(lib.dlwp_linear_packed_bytes(n, k))
+    if nbytes == 0:
+        raise _lib.DlwpError(f"linear: unsupported shape out={n} in={k} (need in % 32 == 0 and out % 4 == 0)")
+    out = torch.empty((*x.shape[:-1], n), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        packed = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device)
+        _lib.check(lib.dlwp_linear_pack_f32(weight.data_ptr(), n, k, packed.data_ptr(), _lib.stream_ptr()), "dlwp_linear_pack_f32")
+        _lib.check(lib.dlwp_linear_f32(x.data_ptr(), packed.data_ptr(), bias.contiguous().data_ptr() if bias is not None else None,
+                                       None, out.data_ptr(), x.numel() // k, k, n, 0, _lib.stream_ptr()), "dlwp_linear_f32")
+    return out
+
+
 def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, precision: str = "fp32", out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """act(x @ m.weight.T + m.bias) + resid over the last dimension in one launch; act 0 none / 1 exact GELU.
@@ -730,7 +785,11 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
         raise _lib.DlwpError(f"linear: unknown precision {precision!r}")
     from . import training as _T
     if _T.wants_grad(x, m.weight, m.bias, resid):
-        y = torch.nn.functional.linear(x, m.weight, m.bias)
+        rows = x.numel() // max(x.shape[-1], 1)
+        if x.is_cuda and x.dtype == torch.float32 and _T._LinearFn.supported(rows, m.in_features, m.out_features):
+            y = _T.linear_fn(x, m.weight, m.bias)         # HIP GEMMs forward and backward (training._LinearFn)
+        else:
+            y = torch.nn.functional.linear(x, m.weight, m.bias)
         if act == 1:
             y = torch.nn.functional.gelu(y)
         elif act != 0:
@@ -781,6 +840,16 @@ def linear(x: torch.Tensor, m: torch.nn.Linear, act: int = 0, resid: Optional[to
                                       resid.data_ptr() if resid is not None else None, out.data_ptr(), x.numel() // k, k, n,
                                       int(act), _lib.stream_ptr()), name)
     return out
+
+
+def linear_any(x: torch.Tensor, m: torch.nn.Linear, act: int = 0) -> torch.Tensor:
+    """act(m(x)) for any Linear: through linear() (HIP kernel; with gradients wanted its differentiable form) on a GPU, the
+    module itself elsewhere (CPU construction / registry tests) or when the kernel does not take the shape."""
+    from . import training as _T
+    if x.is_cuda and x.dtype == torch.float32 and (_T.wants_grad(x, m.weight, m.bias) or linear_supported(m.in_features, m.out_features)):
+        return linear(x, m, act=act)
+    y = m(x)
+    return torch.nn.functional.gelu(y) if act == 1 else y
 
 
 LINEAR_FORMS = ("bf16x6", "f16x3", "bf16", "rocblas")

@@ -242,7 +242,22 @@ class _WindowAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        """HIP backward (dlwp_window_attn_bwd_f32): scores recomputed tile by tile, no [B, heads, N, N] tensor.  Descriptors the
+        kernel does not cover (a bias column that does not fit LDS) and DLWP_TRAIN_TORCH_BACKWARD=1 (the cross-check the tests
+        use) take the torch recomputation below."""
+        from . import ops
+
         qkv, qkv_bias, table = ctx.saved_tensors
+        if not _TORCH_BACKWARD():
+            try:
+                gq, gb, gt = ops.window_attention_backward(qkv, qkv_bias, table, ctx.spec, grad_out)
+                if qkv_bias is not None and gb is None:
+                    gb = torch.zeros_like(qkv_bias) if ctx.needs_input_grad[1] else None
+                return (gq if ctx.needs_input_grad[0] else None, gb if ctx.needs_input_grad[1] else None,
+                        gt if ctx.needs_input_grad[2] else None, None, None)
+            except _lib.DlwpError as e:
+                if "status -4" not in str(e):        # DLWP_ERR_UNSUPPORTED only
+                    raise
         with torch.enable_grad():
             q_ = qkv.detach().requires_grad_(ctx.needs_input_grad[0])
             b_ = qkv_bias.detach().requires_grad_(ctx.needs_input_grad[1]) if qkv_bias is not None else None
@@ -255,6 +270,12 @@ class _WindowAttentionFn(torch.autograd.Function):
         for t, need in ((q_, ctx.needs_input_grad[0]), (b_, ctx.needs_input_grad[1]), (t_, ctx.needs_input_grad[2])):
             res.append(grads.pop(0) if (need and t is not None) else None)
         return res[0], res[1], res[2], None, None
+
+
+def _TORCH_BACKWARD() -> bool:
+    import os
+
+    return os.environ.get("DLWP_TRAIN_TORCH_BACKWARD", "0") == "1"
 
 
 def window_attention(qkv, qkv_bias, table, spec, precision="fp32"):
@@ -372,6 +393,53 @@ class _Conv3x3Fn(torch.autograd.Function):
 
 def conv3x3(x0, weight, bias, act=0, x1=None, pre_act=0, resid=None, hpx=False):
     return _Conv3x3Fn.apply(x0, x1, weight, bias, resid, pre_act, act, hpx)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with the HIP Linear kernel in BOTH directions (reference backward: scripts/train.py:271 through the
+    nn.Linear layers of swin_transformer.py:21-39, :107-120 and panguweather.py:176-211): the fp32-accurate GEMM of
+    csrc/linear.hip (bf16x6) computes the output, the input gradient dX = dY W (the same kernel on the transposed weight) and
+    the weight gradient dW = dY^T X (the same kernel with dY^T as the activation and X^T as the "weight"; the reduction runs
+    over the tokens).  The bias gradient is a column sum.  Shapes the kernel does not take (in / out features not multiples
+    of 32 / 4 in the roles they play in the three products) use the torch operator."""
+
+    @staticmethod
+    def supported(rows: int, k: int, n: int) -> bool:
+        from . import ops
+
+        return (ops.linear_supported(k, n) and ops.linear_supported(n, k) and ops.linear_supported(rows, k) and
+                not _TORCH_BACKWARD())
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import ops
+
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        with torch.no_grad():
+            return ops.linear_raw(x.detach(), weight.detach(), bias.detach() if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+
+        x, weight = ctx.saved_tensors
+        n, k = weight.shape
+        gy2 = gy.reshape(-1, n).contiguous()
+        x2 = x.reshape(-1, k)
+        gx = gw = gb = None
+        with torch.no_grad():
+            if ctx.needs_input_grad[0]:
+                gx = ops.linear_raw(gy2, weight.t().contiguous(), None).view(x.shape)          # [M, N] x [K, N]^T
+            if ctx.needs_input_grad[1]:
+                gw = ops.linear_raw(gy2.t().contiguous(), x2.t().contiguous(), None)             # [N, M] x [K, M]^T -> [N, K]
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = gy2.sum(dim=0)
+        return gx, gw, gb
+
+
+def linear_fn(x, weight, bias):
+    return _LinearFn.apply(x, weight, bias)
 
 
 def wants_grad(*tensors) -> bool:

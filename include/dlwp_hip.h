@@ -245,6 +245,22 @@ int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* desc, const float* qkv_dev,
                               const float* qkv_bias_dev, const float* table_dev, float* out_dev,
                               int32_t batch, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Backward of dlwp_window_attn_f32 (csrc/window_attn_bwd.hip): what loss.backward() of reference scripts/train.py:263-271
+ * runs through WindowAttention.forward (swin_transformer.py:122-154, :217-251) / EarthAttention3D.forward
+ * (panguweather.py:176-211, :285-316), without their Linears.  Flash-style: scores are recomputed per 32 x 32 tile from
+ * qkv and per-row statistics; no N x N tensor exists.  fp32 arithmetic.
+ *   grad_out_dev      [B, L, C]      gradient of the attention output (same token order as out_dev)
+ *   grad_qkv_dev      [B, L, 3 C]    written (zeroed inside; dq arrives through float atomics)
+ *   grad_qkv_bias_dev [3 C] or NULL  gradient that reaches the qkv bias through ZERO-PADDED tokens (they carry q = k = v =
+ *                                    bias); required when the descriptor pads, written (zeroed inside)
+ *   grad_table_dev    like table_dev written (zeroed inside)
+ *   workspace_dev     dlwp_window_attn_bwd_workspace_bytes(desc, batch) bytes: {row max, row sum, delta} per window row */
+size_t dlwp_window_attn_bwd_workspace_bytes(const dlwp_wattn_desc* desc, int32_t batch);
+int32_t dlwp_window_attn_bwd_f32(const dlwp_wattn_desc* desc, const float* qkv_dev, const float* qkv_bias_dev,
+                                 const float* table_dev, const float* grad_out_dev, float* grad_qkv_dev,
+                                 float* grad_qkv_bias_dev, float* grad_table_dev, int32_t batch, void* workspace_dev,
+                                 size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * AFNO2D frequency-domain mixing (reference models/fourcastnet/fourcastnet.py:87-121): complex
  * block-diagonal 2-layer MLP with ReLU, mode truncation and softshrink over the rfft2 spectrum.
