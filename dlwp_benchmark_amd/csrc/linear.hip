@@ -39,6 +39,18 @@ namespace lin {
 
 constexpr int BM = 128, BK = 32;
 
+#ifndef DLWP_RING_LDPOL
+#define DLWP_RING_LDPOL ""        // cache policy of the operand DMAs (A/B: " nt", " sc0", " sc1")
+#endif
+#ifndef DLWP_RING_STPOL
+#define DLWP_RING_STPOL " nt"     // cache policy of the output stores: streamed past the L2 -- the 200-600 MB an output tensor writes
+#endif                            // evicted the x slab / W panel the next tiles re-read from it (C5 l2 qkv 124 -> 97 us, A/B r03m)
+#ifndef DLWP_RING_PATCH
+#define DLWP_RING_PATCH 1         // 1: whole-line stores through a per-wave LDS patch; 0: straight from the accumulator layout
+#endif
+#ifndef DLWP_LIN_STPOL
+#define DLWP_LIN_STPOL " nt"      // the same for linear_kernel's fp32 stores (16 bytes per lane, 64-byte runs: f16x3 qkv 280 -> 253 us;
+#endif                            // NOT its 8-byte bf16 stores: partial lines streamed past the L2 cost 2-3x, A/B r03n)
 struct Params {
   const float* x;              // [M][K]
   const unsigned short* w;     // bf16 parts [3][N][K]
@@ -55,7 +67,7 @@ struct Params {
 // The hardware reads the data at issue; it only asks for wait states before a write to the registers of a wide store
 // (the trailing s_nop 1, checked by tools/asm_hazard_check.py rule C).
 __device__ __forceinline__ void store4(float* dst, const f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off" DLWP_LIN_STPOL "\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 }
 
 __device__ __forceinline__ void store2(unsigned short* dst, const uint2& v) {
@@ -74,8 +86,11 @@ struct Cursor {          // one (tile, k-step) position of this workgroup's flat
 // XB16 / OB16 (bf16-operand form only): x is ALREADY bf16 [M][K] / the output is stored as bf16 [M][N].  The MLP of a block
 // in the bf16 form hands its hidden activation from fc1 to fc2 this way: fc2 rounds its input to bf16 anyway, so the
 // result is bit-identical and the widest tensor of the block crosses HBM at half the bytes in both directions.
+#ifndef DLWP_LIN_WAVES_NP1
+#define DLWP_LIN_WAVES_NP1 2     // resident workgroups per CU the bf16-operand form is compiled for (A/B: tools/ab_build2.sh)
+#endif
 template <int BN, int NP, bool F16 = false, bool XB16 = false, bool OB16 = false>
-__global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
+__global__ __launch_bounds__(256, NP == 1 ? DLWP_LIN_WAVES_NP1 : 2) void linear_kernel(const Params p) {
   static_assert(!(XB16 || OB16) || (NP == 1 && !F16), "bf16 in / out exists for the bf16-operand form");
   constexpr int XQ = XB16 ? 2 : 4;                   // 16-byte x loads per thread and k-step
   constexpr int TN = BN / 32;                        // 16-row W tiles per wave (wave tile: 64 m x BN/2 n)
@@ -378,6 +393,421 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the prefetches issued past the end
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16-operand form with a bf16 x tensor (dlwp_linear_bf16_io, x_is_bf16) -- "ring" kernel (round 3).
+//
+// What bounded linear_kernel at the Swin / Pangu block shapes in their bf16 form (M = 65 536 ... 262 144 rows, K = 96 ... 1 536;
+// knock-out builds, profiles/r03_linear_knockouts.txt): NOT the matrix instructions (removing them changed nothing) and not the
+// epilogue arithmetic, but the memory operations and the way one wave's vmcnt queue couples them -- vmcnt retires in order, so
+// (a) the wait for the next operand stage also waited for the output stores of the tile just finished, (b) hipcc's wait for the
+// epilogue's bias / residual loads drained every operand stage in flight, once per output tile, and (c) 128 x 128 tiles stage
+// 196 KB of operands per 16 K outputs through a path (L2 -> LDS) that moves ~18 TB/s chip-wide at best.
+//
+// This kernel: 256 x BN tiles (8 waves = 4 x 2, a wave owns 64 x BN/2 as before: a quarter less staging per output), BOTH
+// operands by LDS-DMA into a RING of S stages, S - 1 k-steps ahead, ONE barrier per k-step; and EVERY memory operation of a wave
+// is inline asm with a statically known count, so that each wait names exactly what it needs:
+//   * operand stage t:   all but the DMAs of stages t + 1 .. t + S - 2 AND the foreign operations (epilogue loads, stores) issued
+//                        in the last S - 1 steps -- those are younger than the stage's DMA and may stay in flight;
+//   * bias / residual:   requested DL <= 4 steps BEFORE the epilogue that uses them (asm loads into registers held until then),
+//                        awaited with the count of the DMAs issued since;
+//   * output stores:     buffer_store with the range check of the descriptor (rows past M and columns past N get an offset
+//                        beyond num_records and are dropped): always issued, never branched around -- a static count.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BMR = 256;
+
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {      // s_waitcnt takes an immediate: one scalar jump over 64 cases
+  switch (n < 63 ? n : 63) {
+#define DLWP_W1(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define DLWP_W8(k) DLWP_W1(k) DLWP_W1(k + 1) DLWP_W1(k + 2) DLWP_W1(k + 3) DLWP_W1(k + 4) DLWP_W1(k + 5) DLWP_W1(k + 6) DLWP_W1(k + 7)
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
+    case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
+    case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
+    case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+    case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
+    case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
+    case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
+    case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    case 57: asm volatile("s_waitcnt vmcnt(57)" ::: "memory"); break;
+    case 58: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
+    case 59: asm volatile("s_waitcnt vmcnt(59)" ::: "memory"); break;
+    case 60: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+    case 61: asm volatile("s_waitcnt vmcnt(61)" ::: "memory"); break;
+    case 62: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+#undef DLWP_W8
+#undef DLWP_W1
+  }
+}
+
+template <int BN, bool OB16, int S, bool RES>
+__global__ __launch_bounds__(512, 1) void linear_ring_kernel(const Params p) {
+  // k-steps of 64: a tile row is 128 bytes = ONE request of the vector L1 for a whole line.  The L1's outstanding-request slots
+  // times the L2 latency are what bound this kernel (profiles/r03_linear_pmc_mem.txt: the L1 stalled "pending" 61 % of the time,
+  // 0.17 requests per clock and CU at a read latency of 430 cycles): the same bytes in half the requests.
+  constexpr int BKR = 64, ROWB = 2 * BKR;            // bytes per tile row
+  constexpr int TN = BN / 32;
+  constexpr int XP = BMR / 8, WP = BN / 8;           // 1 KiB pieces (8 rows x 128 bytes) per stage
+  constexpr int GX = XP / 8, GW = (WP + 7) / 8;      // pieces per wave and stage
+  constexpr int GD = GX + GW;                        // DMAs a wave issues per step
+  constexpr int XBYTES = BMR * ROWB, STAGE = XBYTES + BN * ROWB;
+  constexpr int NFLY = GD * (S - 2);                 // DMAs that may stay in flight when stage t is needed
+  constexpr int EL = TN + (RES ? 4 * TN : 0);        // epilogue loads of a wave and tile (bias, residual rows)
+#if DLWP_RING_PATCH
+  constexpr int ES = OB16 ? 8 : 8 * ((TN + 1) / 2);  // output stores of a wave and tile (whole-line stores through the LDS patch)
+#else
+  constexpr int ES = 4 * TN;                         // output stores of a wave and tile
+#endif
+  static_assert(S >= 3 && S <= 8 && NFLY + EL + ES <= 63, "ring depth / counted waits");
+  extern __shared__ __align__(1024) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int wm = wave & 3, wn = wave >> 2;
+  const unsigned short* xg = reinterpret_cast<const unsigned short*>(p.x);
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const long long tiles_m = (p.M + BMR - 1) / BMR;
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int slabs = tiles_m > xcd ? (int)((tiles_m - xcd + 7) / 8) : 0;
+  const int ntile = slabs * tiles_n;
+  if (ntile <= li) return;
+  const int my_tiles = (ntile - li + per_xcd - 1) / per_xcd;
+  const int nk = p.K / BKR;                                    // >= 3 (host)
+  const long long total = (long long)my_tiles * nk;
+  const int dq = per_xcd / tiles_n, dr = per_xcd % tiles_n;
+  auto advance = [&](Cursor& c) -> bool {
+    if (++c.ks < nk) return false;
+    c.ks = 0;
+    if (c.left == 0) return false;
+    --c.left;
+    c.slab += dq;
+    c.nt += dr;
+    if (c.nt >= tiles_n) { c.nt -= tiles_n; ++c.slab; }
+    return true;
+  };
+  auto row0 = [&](const Cursor& c) -> long long { return ((long long)c.slab * 8 + xcd) * BMR; };
+
+  // LDS image: rows of 128 bytes = 8 chunks of 16; chunk c of row r sits at position c ^ ((r >> 1) & 7): the ds_read_b128
+  // operand reads (lane groups {0-3, 12-15, 20-27}, ... = rows j of one 16-row block at chunk 4 h + g) then touch 16 different
+  // 16-byte slots of the 256-byte bank row.  LDS-DMA writes lane-linear pieces: the swizzle is applied to the SOURCE address.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned xoff[GX], xdst[GX], woff[GW], wdst[GW];
+  auto rows_of = [&](const Cursor& c) {
+    const int r = lane >> 3, pos = lane & 7;
+#pragma unroll
+    for (int i = 0; i < GX; ++i) {
+      const int pc = wave + 8 * i;
+      const long long left = p.M - 1 - row0(c);                    // rows past M: clamped to the last row, never stored
+      const int rr = 8 * pc + r;
+      const int row = rr < left ? rr : (int)left;
+      xoff[i] = ((unsigned)row * (unsigned)p.K + 8u * (pos ^ ((rr >> 1) & 7))) * 2u;
+      xdst[i] = lds0 + pc * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+      int pc = wave + 8 * i;
+      if (pc >= WP) pc -= 8;                                       // a wave past the last piece repeats its previous one
+      if (pc < 0 || pc >= WP) pc = wave % WP;
+      const int rr = 8 * pc + r;
+      const int nn = c.nt * BN + rr;
+      const int n = nn < p.N ? nn : p.N - 1;
+      woff[i] = ((unsigned)n * (unsigned)p.K + 8u * (pos ^ ((rr >> 1) & 7))) * 2u;
+      wdst[i] = lds0 + XBYTES + pc * 1024;
+    }
+  };
+  auto dma = [&](int slot, const Cursor& c) {
+    const unsigned short* xb = xg + row0(c) * p.K + c.ks * BKR;
+    const unsigned short* wb = p.w + c.ks * BKR;
+#pragma unroll
+    for (int i = 0; i < GX; ++i) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(xdst[i] + slot * STAGE);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" DLWP_RING_LDPOL "\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(xoff[i]), "s"(xb), "s"(dst) : "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(wdst[i] + slot * STAGE);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" DLWP_RING_LDPOL "\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(woff[i]), "s"(wb), "s"(dst) : "memory");
+    }
+  };
+
+  f32x4 acc[4][TN];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Cursor cc, cl;
+  cc.slab = li / tiles_n; cc.nt = li % tiles_n; cc.ks = 0; cc.left = my_tiles - 1;
+  cl = cc;
+  rows_of(cl);
+#pragma unroll
+  for (int s0 = 0; s0 < S - 1; ++s0) {       // stages 0 .. S-2 (past the end: the last tile again, results unused)
+    dma(s0, cl);
+    if (advance(cl)) rows_of(cl);
+  }
+  // operand fragments: row j of a 16-row block, chunk 4 h + g (k-half h), at its swizzled position
+  const int fsw = (j >> 1) & 7;
+  const unsigned char* xfrag = smem + (wm * 64 + j) * ROWB;
+  const unsigned char* wfrag = smem + XBYTES + (wn * (BN / 2) + j) * ROWB;
+  const int ch0 = (g ^ fsw) << 4, ch1 = ((4 + g) ^ fsw) << 4;
+
+  // ---- epilogue operands, requested DL steps ahead: clamped addresses, always EL loads per wave
+  const int DL = nk - 1 < 2 ? nk - 1 : 2;
+  f32x4 bv[TN], rs[RES ? 4 : 1][TN];
+  const float* zero4 = p.bias ? p.bias : p.x;       // (a valid 16-byte aligned address for the loads of an absent bias: values unused)
+  auto epi_request = [&]() {
+    const long long mbase = row0(cc) + wm * 64 + j;
+    const int nbase = cc.nt * BN + wn * (BN / 2) + 4 * g;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int ncl = nbase + 16 * b < p.N ? nbase + 16 * b : p.N - 4;
+      const float* src = p.bias ? p.bias + ncl : zero4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[b]) : "v"(src) : "memory");
+    }
+    if constexpr (RES) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const long long m = mbase + 16 * a < p.M ? mbase + 16 * a : p.M - 1;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int ncl = nbase + 16 * b < p.N ? nbase + 16 * b : p.N - 4;
+          const float* src = p.resid + m * p.N + ncl;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rs[a][b]) : "v"(src) : "memory");
+        }
+      }
+    }
+  };
+  // output buffer descriptor: raw buffer, range-checked against the tensor's bytes (stores beyond are dropped by the hardware)
+  const unsigned long long out_bytes = (unsigned long long)p.M * p.N * (OB16 ? 2 : 4);
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(out_bytes < 0xFFFFFFF0ull ? out_bytes : 0xFFFFFFF0ull), 0x00020000);
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const long long mbase = row0(cc) + wm * 64 + j;
+    const int nbase = cc.nt * BN + wn * (BN / 2) + 4 * g;
+    // the operands requested DL steps ago: younger in the queue are the DMAs of the steps since (this step's included)
+    wait_vmcnt_dyn(GD * DL);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) asm volatile("" : "+v"(bv[b]));
+    if constexpr (RES) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) asm volatile("" : "+v"(rs[a][b]));
+    }
+#if !DLWP_RING_PATCH
+    {
+      const long long mbase = row0(cc) + wm * 64 + j;
+      const int nbase = cc.nt * BN + wn * (BN / 2) + 4 * g;
+#pragma unroll
+      for (int a = 0; a < 4; a += 2) {
+        const long long m_u = mbase + 16 * a, m_v = m_u + 16;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x4 u = acc[a][b], v = acc[a + 1][b];
+          if (p.bias) { u += bv[b]; v += bv[b]; }
+          if (p.act) gelu_erf8_fma(u, v);
+          if constexpr (RES) {
+            u += rs[a][b];
+            v += rs[a + 1][b];
+          }
+          const int n = nbase + 16 * b;
+          const bool okn = n < p.N;
+          const unsigned off_u = (okn && m_u < p.M) ? (unsigned)((m_u * p.N + n) * (OB16 ? 2 : 4)) : 0xFFFFFFF0u;
+          const unsigned off_v = (okn && m_v < p.M) ? (unsigned)((m_v * p.N + n) * (OB16 ? 2 : 4)) : 0xFFFFFFF0u;
+          if constexpr (OB16) {
+            const uint2 pu = uint2{cvt_pk_bf16(u[0], u[1]), cvt_pk_bf16(u[2], u[3])}, pv = uint2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+            asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" DLWP_RING_STPOL "\n\ts_nop 1" : : "v"(pu), "v"(off_u), "s"(orsrc) : "memory");
+            asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" DLWP_RING_STPOL "\n\ts_nop 1" : : "v"(pv), "v"(off_v), "s"(orsrc) : "memory");
+          } else {
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" DLWP_RING_STPOL "\n\ts_nop 1" : : "v"(u), "v"(off_u), "s"(orsrc) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" DLWP_RING_STPOL "\n\ts_nop 1" : : "v"(v), "v"(off_v), "s"(orsrc) : "memory");
+          }
+        }
+      }
+    }
+#else
+    // Results leave through a 2 KB per-wave LDS patch that turns the accumulator layout (a lane: 4 columns of one row; an
+    // instruction: 16 rows x 64 or 32 bytes) into whole 128-byte lines (an instruction: 8 rows x 128 bytes): a quarter (bf16) /
+    // half (fp32) of the write requests for the same bytes -- requests, not bytes, are what the vector L1 runs out of.
+    unsigned char* patch = smem + S * STAGE + wave * 2048;
+    const int rrow = lane >> 3, rchunk = lane & 7;             // read-back role: row (of 8), 16-byte chunk (of 8)
+
+    const long long mrow = row0(cc) + wm * 64;                  // first row of the wave's tile
+    const int ncol = cc.nt * BN + wn * (BN / 2);                // first column
+#pragma unroll
+    for (int a = 0; a < 4; a += 2) {
+      f32x4 u[TN], v[TN];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        u[b] = acc[a][b];
+        v[b] = acc[a + 1][b];
+        if (p.bias) { u[b] += bv[b]; v[b] += bv[b]; }
+        if (p.act) gelu_erf8_fma(u[b], v[b]);
+        if constexpr (RES) {
+          u[b] += rs[a][b];
+          v[b] += rs[a + 1][b];
+        }
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {                   // row block a + half: rows 16 (a + half) .. + 15 of the wave's tile
+        const f32x4 (&w)[TN] = half ? v : u;
+        const long long m0 = mrow + 16 * (a + half);
+        if constexpr (OB16) {
+          // patch = [16 rows][128 bytes]: this lane's 4 bf16 of column block b at row j, byte 2 (16 b + 4 g)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            *reinterpret_cast<uint2*>(patch + j * 128 + 2 * (16 * b + 4 * g)) = uint2{cvt_pk_bf16(w[b][0], w[b][1]), cvt_pk_bf16(w[b][2], w[b][3])};
+          asm volatile("" ::: "memory");       // other lanes' writes are read below: one wave's LDS operations complete in order
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            const int row = 8 * rb + rrow;
+            const u32x4 d = *reinterpret_cast<const u32x4*>(patch + row * 128 + 16 * rchunk);
+            const int n = ncol + 8 * rchunk;
+            const bool ok = (m0 + row < p.M) && (8 * rchunk < BN / 2) && (n < p.N);     // (N % 4 == 0; bf16 rows: N % 8 asked by the host)
+            const unsigned off = ok ? (unsigned)(((m0 + row) * p.N + n) * 2) : 0xFFFFFFF0u;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen" DLWP_RING_STPOL "\n\ts_nop 1" : : "v"(d), "v"(off), "s"(orsrc) : "memory");
+          }
+          asm volatile("" ::: "memory");
+        } else {
+          // column-block pairs: patch = [16 rows][32 floats]
+#pragma unroll
+          for (int bp = 0; bp < TN; bp += 2) {
+            *reinterpret_cast<f32x4*>(patch + j * 128 + 4 * (4 * g)) = w[bp];
+            if (bp + 1 < TN) *reinterpret_cast<f32x4*>(patch + j * 128 + 4 * (16 + 4 * g)) = w[bp + 1];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+              const int row = 8 * rb + rrow;
+              const f32x4 d = *reinterpret_cast<const f32x4*>(patch + row * 128 + 16 * rchunk);
+              const int n = ncol + 16 * bp + 4 * rchunk;
+              const bool ok = (m0 + row < p.M) && (16 * bp + 4 * rchunk < BN / 2) && (n < p.N);
+              const unsigned off = ok ? (unsigned)(((m0 + row) * p.N + n) * 4) : 0xFFFFFFF0u;
+              asm volatile("s_waitcnt lgkmcnt(0)\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen" DLWP_RING_STPOL "\n\ts_nop 1" : : "v"(d), "v"(off), "s"(orsrc) : "memory");
+            }
+            asm volatile("" ::: "memory");
+          }
+        }
+      }
+    }
+#endif
+
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // foreign operations (epilogue loads, stores) issued in each of the last S - 1 steps: they are younger than the DMA of the
+  // stage a step needs (issued S - 1 steps before it, ahead of that step's foreign operations) and stay out of its wait
+  int fo[S - 1];
+#pragma unroll
+  for (int i = 0; i < S - 1; ++i) fo[i] = 0;
+  int slot = 0;                                        // slot of stage t; stage t + S - 1 goes into the slot of stage t - 1
+  for (long long t = 0; t < total; ++t) {
+    int extra = 0;
+#pragma unroll
+    for (int i = 0; i < S - 1; ++i) extra += fo[i];
+    wait_vmcnt_dyn(NFLY + extra);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned char* xf = xfrag + slot * STAGE;
+    const unsigned char* wf = wfrag + slot * STAGE;
+    u32x4 xb[2][4], wa[2][TN];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      xb[0][a] = *reinterpret_cast<const u32x4*>(xf + a * (16 * ROWB) + ch0);
+      xb[1][a] = *reinterpret_cast<const u32x4*>(xf + a * (16 * ROWB) + ch1);
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      wa[0][b] = *reinterpret_cast<const u32x4*>(wf + b * (16 * ROWB) + ch0);
+      wa[1][b] = *reinterpret_cast<const u32x4*>(wf + b * (16 * ROWB) + ch1);
+    }
+    {
+      const int free_slot = slot == 0 ? S - 1 : slot - 1;
+      dma(free_slot, cl);
+      if (advance(cl)) rows_of(cl);
+    }
+    int issued = 0;
+    if (cc.ks == nk - 1 - DL) {          // this tile's bias / residual rows, DL steps before they are needed
+      epi_request();
+      issued += EL;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][b] = mfma16x16x32_bf16(wa[h][b], xb[h][a], acc[a][b]);
+    __builtin_amdgcn_s_setprio(0);
+    if (cc.ks == nk - 1) {
+      epilogue();
+      issued += ES;
+    }
+    advance(cc);
+#pragma unroll
+    for (int i = S - 2; i > 0; --i) fo[i] = fo[i - 1];
+    fo[0] = issued;
+    slot = slot + 1 == S ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // weights [N][K] fp32 -> the two f16 images [N][K] of the f16x3 form (wh = f16(w 2^s), wm' = (w 2^s - wh) * 2^11); scale[0] holds the
 // bits of max |w|, scale[1] receives 2^-(11+s)
 __global__ __launch_bounds__(256) void linear_pack_f16_kernel(const float* __restrict__ w, unsigned short* __restrict__ h,
@@ -440,8 +870,53 @@ static int32_t launch_v2(const Params& p, hipStream_t s) {
   return DLWP_OK;
 }
 
+template <int BN, bool OB16, int S, bool RES>
+static int32_t launch_ring(const Params& p, hipStream_t s) {
+  static std::atomic<int> slots_of[64];
+  constexpr size_t lds = (size_t)S * (BMR * 128 + BN * 128) + 8 * 2048;     // ring + the per-wave store patches
+  auto kern = linear_ring_kernel<BN, OB16, S, RES>;
+  int dev = 0;
+  DLWP_HIP_CHECK(hipGetDevice(&dev));
+  DLWP_REQUIRE(dev >= 0 && dev < 64, DLWP_ERR_UNSUPPORTED, "linear: device ordinal %d", dev);
+  int slots = slots_of[dev].load(std::memory_order_relaxed);
+  if (!slots) {
+    DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int cus = 0, per_cu = 0;
+    DLWP_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    DLWP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds));
+    DLWP_REQUIRE(per_cu > 0 && cus >= 8, DLWP_ERR_UNSUPPORTED, "linear: kernel does not fit on this device");
+    slots = cus * per_cu;
+    slots_of[dev].store(slots, std::memory_order_relaxed);
+  }
+  const long long tiles_m = (p.M + BMR - 1) / BMR, tiles_n = (p.N + BN - 1) / BN;
+  long long per_xcd = ((tiles_m + 7) / 8) * tiles_n;
+  DLWP_REQUIRE(per_xcd < (1ll << 30) && 3ll * p.wpart * 2 < (1ll << 31) && (long long)BMR * p.K * 4 < (1ll << 31) &&
+                   (long long)p.M * p.N * 4 < 0xFFFFFFF0ll,
+               DLWP_ERR_UNSUPPORTED, "linear: operand too large for 32-bit tile offsets");
+  if (per_xcd > slots / 8) per_xcd = slots / 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * per_xcd)), dim3(512), lds, s, p);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
+#ifndef DLWP_LIN_RING_STAGES
+#define DLWP_LIN_RING_STAGES 3
+#endif
+
 // form 3: fp32-accurate (six bf16 products), 2: fp32-grade f16x3 (three f16 products), 1: bf16 operands
 static int32_t launch(const Params& p, int form, hipStream_t s) {
+  static const bool ring = !(getenv("DLWP_LINEAR_RING") && atoi(getenv("DLWP_LINEAR_RING")) == 0);      // A/B: 0 = the register-staged kernel for bf16 x as well
+  // the ring kernel where its 256-row tiles fill the chip several times over (one 512-thread workgroup per CU); smaller calls
+  // (Swin stage 1: 16 384 rows) keep linear_kernel's 128-row tiles at two workgroups per CU
+  const long long ring_tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+  if (ring && (form == 4 || form == 6) && p.K % 64 == 0 && p.K >= 3 * 64 && (form == 4 || p.N % 8 == 0) && ring_tiles >= 1024) {
+    const bool narrow_r = (p.N % 128) != 0 && (p.N % 128) <= 96 && (p.N % 96 == 0 || p.N < 128);
+    constexpr int S = DLWP_LIN_RING_STAGES;
+#define DLWP_RING(BN_, OB_) (p.resid ? launch_ring<BN_, OB_, S, true>(p, s) : launch_ring<BN_, OB_, S, false>(p, s))
+    if (form == 4) return narrow_r ? DLWP_RING(96, false) : DLWP_RING(128, false);
+    return narrow_r ? DLWP_RING(96, true) : DLWP_RING(128, true);
+#undef DLWP_RING
+  }
   // 96-wide W tiles where 128 would waste a quarter or more of the last tile (N = 96, 192, 288, 576, 1152)
   const bool narrow = (p.N % 128) != 0 && (p.N % 128) <= 96 && (p.N % 96 == 0 || p.N < 128);
   if (form == 3) return narrow ? launch_v2<96, 3>(p, s) : launch_v2<128, 3>(p, s);

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring of the shape label")
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16", "f16x3"))
+    ap.add_argument("--io", action="store_true", help="bf16 precision: the tensors cross HBM as the blocks hand them over -- qkv / fc1 "
+                                                       "take a bf16 x (LayerNorm output), fc1 writes bf16, fc2 reads it")
     args = ap.parse_args()
     dev = "cuda:0"
     print(f"{'shape':18s} {'rows':>8s} {'in':>5s} {'out':>5s} | {'hip us':>8s} {'TF/s(6x)':>9s} | {'torch us':>9s} | err hip / torch")
@@ -50,9 +52,15 @@ def main():
         x = torch.randn(rows, k, device=dev)
         r = torch.randn(rows, n, device=dev) if resid else None
         out = torch.empty(rows, n, device=dev)
+        xin, oo = x, out
+        if args.io and args.precision == "bf16":
+            if "proj" not in label:
+                xin = x.to(torch.bfloat16)                      # LayerNorm output / GELU hidden handed over as bf16
+            if "fc1" in label:
+                oo = torch.empty(rows, n, device=dev, dtype=torch.bfloat16)
         with torch.no_grad():
             def hip():
-                ops.linear(x, m, act=act, resid=r, out=out, precision=args.precision)
+                ops.linear(xin, m, act=act, resid=r, out=oo, precision=args.precision)
 
             def ref():
                 y = torch.nn.functional.linear(x, m.weight, m.bias)
@@ -70,10 +78,13 @@ def main():
             if resid:
                 want = want + r[sub].double()
             hip()
-            e_hip = ((out[sub].double() - want).norm() / want.norm()).item()
+            e_hip = ((oo[sub].double() - want).norm() / want.norm()).item()
             e_ref = ((ref()[sub].double() - want).norm() / want.norm()).item()
-        tf = 6 * 2.0 * rows * k * n / (t_hip * 1e-6) / 1e12
-        print(f"{label:18s} {rows:8d} {k:5d} {n:5d} | {t_hip:8.1f} {tf:9.1f} | {t_ref:9.1f} | {e_hip:.1e} / {e_ref:.1e}", flush=True)
+        prods = {"fp32": 6, "f16x3": 3, "bf16": 1}[args.precision]
+        tf = prods * 2.0 * rows * k * n / (t_hip * 1e-6) / 1e12
+        nbytes = xin.numel() * xin.element_size() + oo.numel() * oo.element_size() + (r.numel() * 4 if resid else 0)
+        print(f"{label:18s} {rows:8d} {k:5d} {n:5d} | {t_hip:8.1f} {tf:9.1f} | {t_ref:9.1f} | {e_hip:.1e} / {e_ref:.1e} | "
+              f"{nbytes / (t_hip * 1e-6) / 1e12:.2f} TB/s of tensor bytes", flush=True)
 
 
 if __name__ == "__main__":
