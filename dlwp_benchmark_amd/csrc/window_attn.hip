@@ -567,3 +567,20 @@ extern "C" int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* u, const float* 
   }
   return window_attn_impl(u, qkv, qkv_bias, table, out, batch, stream, 1);
 }
+
+// bf16 form with bfloat16 TENSORS: qkv [B, L, 3 C], the qkv bias [3 C] (read for zero-padded tokens) and the output [B, L, C] are
+// bf16.  Only the two fast kernels take this form (every Swin / Pangu block of the reference configurations); for any other
+// descriptor the call returns DLWP_ERR_UNSUPPORTED and the caller hands fp32 tensors to dlwp_window_attn_bf16.
+extern "C" int32_t dlwp_window_attn_bf16_io(const dlwp_wattn_desc* u, const void* qkv_bf16, const void* qkv_bias_bf16,
+                                            const float* table, void* out_bf16, int32_t batch, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  DLWP_REQUIRE(u && qkv_bf16 && table && out_bf16, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0, DLWP_ERR_INVALID_ARGUMENT, "batch must be positive");
+  int32_t rc = wattn2_run(u, reinterpret_cast<const float*>(qkv_bf16), table, reinterpret_cast<float*>(out_bf16), batch, workspace,
+                          workspace_bytes, reinterpret_cast<hipStream_t>(stream), 16);
+  if (rc != 1) return rc;
+  rc = wattn3_run(u, reinterpret_cast<const float*>(qkv_bf16), reinterpret_cast<const float*>(qkv_bias_bf16), table,
+                  reinterpret_cast<float*>(out_bf16), batch, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), 16);
+  if (rc != 1) return rc;
+  return fail(DLWP_ERR_UNSUPPORTED, "window attention with bfloat16 tensors: descriptor not covered by the fast kernels");
+}

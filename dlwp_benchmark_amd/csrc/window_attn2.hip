@@ -44,6 +44,7 @@ struct Geo {
   int heads, d, C, N, nwin;
   int TR, W2;              // table rows (2wlat-1)(2wlon-1), 2wlon-1
   float qscale;            // qk scale * log2 e
+  int io16;                // bf16 form only: qkv and out are bfloat16 tensors (the block's qkv Linear writes bf16, proj reads bf16)
 };
 
 struct Images {           // device pointers into the caller's workspace
@@ -92,14 +93,24 @@ __global__ __launch_bounds__(256) void wattn2_prep_kernel(const Geo G, const flo
     const int A = ilat * G.wlat + zlat, O = ilon * G.wlon + zlon;         // shifted frame
     const int sa = (A + G.sf[0]) % G.lat, so = (O + G.sf[1]) % G.lon;     // shifted[p] = x[(p + sf) mod dim]
     const long long tok = (long long)sa * G.lon + so;
-    const float* src = qkv + ((long long)b * L + tok) * 3 * G.C + (long long)which * G.C + head * G.d;
+    const long long eoff = ((long long)b * L + tok) * 3 * G.C + (long long)which * G.C + head * G.d;
+    const float* src = qkv + eoff;
     float x[8];
     const int e0 = 8 * c;
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = 0.f;
     if (e0 < G.d) {   // d is a multiple of 8: a chunk is entirely inside or outside the head dimension
-      const float4 lo = *reinterpret_cast<const float4*>(src + e0), hi = *reinterpret_cast<const float4*>(src + e0 + 4);
-      x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+      if (G.io16) {
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(qkv) + eoff + e0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[2 * i] = __uint_as_float(raw[i] << 16);
+          x[2 * i + 1] = __uint_as_float(raw[i] & 0xFFFF0000u);
+        }
+      } else {
+        const float4 lo = *reinterpret_cast<const float4*>(src + e0), hi = *reinterpret_cast<const float4*>(src + e0 + 4);
+        x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+      }
       if (which == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] *= G.qscale;
@@ -646,7 +657,12 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
     const int qn = qblk * (64 * SUB) + ql;
     const int dst = I.dest[win * N + qn];
     const float* so = s_o + ql * LDO + e;
-    *reinterpret_cast<float4*>(out_b + (long long)dst * G.C + e) = float4{so[0], so[1], so[2], so[3]};
+    if (G.io16) {
+      unsigned short* o16 = reinterpret_cast<unsigned short*>(out) + ((long long)b * G.lat * G.lon + dst) * G.C + head * d + e;
+      *reinterpret_cast<uint2*>(o16) = uint2{cvt_pk_bf16(so[0], so[1]), cvt_pk_bf16(so[2], so[3])};
+    } else {
+      *reinterpret_cast<float4*>(out_b + (long long)dst * G.C + e) = float4{so[0], so[1], so[2], so[3]};
+    }
   }
 }
 
@@ -687,6 +703,7 @@ static Plan make_plan(const dlwp_wattn_desc* u, int batch, int np) {
   G.heads = u->heads; G.d = d; G.C = u->heads * d; G.N = N; G.nwin = G.nlat * G.nlon;
   G.W2 = 2 * wlon - 1; G.TR = (2 * wlat - 1) * G.W2;
   G.qscale = u->scale * 1.4426950408889634f;
+  G.io16 = 0;
   P.DK = d / 32 + 1; P.DKP = 32 * P.DK;
   P.DB = (d + 15) / 16; P.DVP = 16 * P.DB;
   P.TRP = (G.TR + 3) & ~3;
@@ -732,8 +749,10 @@ static int32_t launch(const Plan& P, const Images& I, float* out, int batch, hip
 }
 
 template <int NP>
-static int32_t run_np(const Plan& P, const float* qkv, const float* table, float* out, int batch, void* workspace,
-                      hipStream_t s) {
+static int32_t run_np(const Plan& P_in, const float* qkv, const float* table, float* out, int batch, void* workspace,
+                      hipStream_t s, int io16 = 0) {
+  Plan P = P_in;
+  P.G.io16 = io16;
   Images I = {};
   char* w = reinterpret_cast<char*>(workspace);
   for (int p = 0; p < NP; ++p) {
@@ -783,12 +802,14 @@ const int* wattn2_fallback_counter(const dlwp_wattn_desc* u, int batch, int np, 
 // returns DLWP_OK, an error, or 1 when this descriptor is not covered (the caller takes the generic kernel)
 int32_t wattn2_run(const dlwp_wattn_desc* u, const float* qkv, const float* table, float* out, int batch, void* workspace,
                    size_t workspace_bytes, hipStream_t s, int np) {
+  const int io16 = np == 16 ? 1 : 0;        // bf16 form with bfloat16 qkv / output tensors
+  if (io16) np = 1;
   const wattn2::Plan P = wattn2::make_plan(u, batch, np);
   if (!P.ok || !workspace || workspace_bytes < P.bytes) return 1;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(qkv) & 15) ||
       (reinterpret_cast<uintptr_t>(out) & 15))
     return 1;
   return np == 3 ? wattn2::run_np<3>(P, qkv, table, out, batch, workspace, s)
-                 : wattn2::run_np<1>(P, qkv, table, out, batch, workspace, s);
+                 : wattn2::run_np<1>(P, qkv, table, out, batch, workspace, s, io16);
 }
 }  // namespace dlwp

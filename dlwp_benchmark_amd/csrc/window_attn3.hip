@@ -69,10 +69,17 @@ __global__ __launch_bounds__(256) void wattn3_table_kernel(const float* __restri
 // region compare per score.  One kernel doing both needed 156 VGPRs for the sake of 9 % of the windows.
 // (<= 128 VGPRs, i.e. four waves per SIMD, matters even where LDS admits only two workgroups per CU: the NP = 3 kernel at 130
 // VGPRs ran 35 % slower than at 126.)
-template <int RP, int PP, int PB, int NP, int MODE>
+// IO16 (bf16 form only, round 3): qkv, the qkv bias and the output are bfloat16 tensors -- the qkv Linear of a block in the bf16
+// form writes bf16 (dlwp_linear_bf16_io) and proj reads bf16, so the widest tensor of the block (qkv: 604 MB per layer-1 call
+// of C5 in fp32) crosses HBM at half the bytes in both directions; K and V chunks go to LDS as they are.
+template <int RP, int PP, int PB, int NP, int MODE, bool IO16 = false>
 __global__ __launch_bounds__(64 * PB) __attribute__((amdgpu_waves_per_eu(PP == 1 ? 4 : 3))) void wattn3_kernel(const Geo G, const float* __restrict__ qkv,
                                                           const float* __restrict__ qkv_bias, const float* __restrict__ tabT,
                                                           float* __restrict__ out, long long L) {
+  static_assert(!IO16 || NP == 1, "bf16 tensors go with the bf16 form");
+  using KV = std::conditional_t<IO16, uint2, float4>;          // one staged chunk: 4 head dims of a K or V row
+  const unsigned short* qkv16 = reinterpret_cast<const unsigned short*>(qkv);
+  const unsigned short* bias16 = reinterpret_cast<const unsigned short*>(qkv_bias);
   constexpr bool MASK = true;
   constexpr int WPL = RP + PP;
   constexpr int KB = WPL * PB;                    // 16-key blocks
@@ -175,11 +182,16 @@ __global__ __launch_bounds__(64 * PB) __attribute__((amdgpu_waves_per_eu(PP == 1
     for (int i = tid; i < 48 * 8; i += NT) {
       const int row = i >> 3, c8 = i & 7;                     // rows 0..15 K, 16..31 V full, 32..47 V tail
       const bool isk = row < 16;
-      const float4 v = *reinterpret_cast<const float4*>(qkv_bias + (isk ? C : 2 * C) + head * D + 4 * c8);
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      uint2 v16 = {0u, 0u};
+      if constexpr (IO16) v16 = *reinterpret_cast<const uint2*>(bias16 + (isk ? C : 2 * C) + head * D + 4 * c8);
+      else v = *reinterpret_cast<const float4*>(qkv_bias + (isk ? C : 2 * C) + head * D + 4 * c8);
       if (!isk && row >= 32 && row - 32 >= tail) continue;
       unsigned short* d = isk ? s_k + (RP * 16 * PB + row) * LDK + 4 * c8 : s_v + (RP * 16 * PB + row - 16) * LDV + 4 * c8;
       const int prow = isk ? KR * LDK : VR * LDV;
-      if constexpr (NP == 3) {
+      if constexpr (IO16) {
+        *reinterpret_cast<uint2*>(d) = v16;
+      } else if constexpr (NP == 3) {
         unsigned h0, m0, l0, h1, m1, l1;
         split3_pair(v.x, v.y, h0, m0, l0);
         split3_pair(v.z, v.w, h1, m1, l1);
@@ -251,7 +263,10 @@ __global__ __launch_bounds__(64 * PB) __attribute__((amdgpu_waves_per_eu(PP == 1
     return (x >= G.plon ? x - G.plon : x) - G.pad_l;
   };
 
-  float4 kreg[CPT], vreg[CPT], qreg[2];
+  KV kreg[CPT], vreg[CPT];
+  float4 qreg[2];
+  u32x4 qraw = {0u, 0u, 0u, 0u};
+  const unsigned short* qkv_b16 = qkv16 + (long long)b * L * 3 * C;
   auto prefetch = [&](int ilon) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -259,20 +274,35 @@ __global__ __launch_bounds__(64 * PB) __attribute__((amdgpu_waves_per_eu(PP == 1
       const bool lon_ok = so >= 0 && so < G.lon;
 #pragma unroll
       for (int r = 0; r < RP; ++r) {
-        const float* row = (lon_ok && st_base[r][i] >= 0) ? qkv_b + (long long)(st_base[r][i] + so) * 3 * C : qkv_bias;
-        kreg[2 * r + i] = *reinterpret_cast<const float4*>(row + C + head * D + 4 * ch);
-        vreg[2 * r + i] = *reinterpret_cast<const float4*>(row + 2 * C + head * D + 4 * ch);
+        const bool real = lon_ok && st_base[r][i] >= 0;
+        if constexpr (IO16) {
+          const unsigned short* row = real ? qkv_b16 + (long long)(st_base[r][i] + so) * 3 * C : bias16;
+          kreg[2 * r + i] = *reinterpret_cast<const uint2*>(row + C + head * D + 4 * ch);
+          vreg[2 * r + i] = *reinterpret_cast<const uint2*>(row + 2 * C + head * D + 4 * ch);
+        } else {
+          const float* row = real ? qkv_b + (long long)(st_base[r][i] + so) * 3 * C : qkv_bias;
+          kreg[2 * r + i] = *reinterpret_cast<const float4*>(row + C + head * D + 4 * ch);
+          vreg[2 * r + i] = *reinterpret_cast<const float4*>(row + 2 * C + head * D + 4 * ch);
+        }
       }
     }
     const int so = src_lon(ilon, q_w);
-    const float* row = (so >= 0 && so < G.lon && q_base >= 0) ? qkv_b + (long long)(q_base + so) * 3 * C : qkv_bias;
-    qreg[0] = *reinterpret_cast<const float4*>(row + head * D + 8 * g);
-    qreg[1] = *reinterpret_cast<const float4*>(row + head * D + 8 * g + 4);
+    const bool qreal = so >= 0 && so < G.lon && q_base >= 0;
+    if constexpr (IO16) {
+      const unsigned short* row = qreal ? qkv_b16 + (long long)(q_base + so) * 3 * C : bias16;
+      qraw = *reinterpret_cast<const u32x4*>(row + head * D + 8 * g);
+    } else {
+      const float* row = qreal ? qkv_b + (long long)(q_base + so) * 3 * C : qkv_bias;
+      qreg[0] = *reinterpret_cast<const float4*>(row + head * D + 8 * g);
+      qreg[1] = *reinterpret_cast<const float4*>(row + head * D + 8 * g + 4);
+    }
   };
   // K row (32 bf16 per part) and V row (+ ones column) of one staged chunk
-  auto put = [&](unsigned short* base, int ld, int part_rows, int slot, const float4& v, bool zero) {
+  auto put = [&](unsigned short* base, int ld, int part_rows, int slot, const KV& v, bool zero) {
     unsigned short* d = base + slot * ld + 4 * ch;
-    if constexpr (NP == 3) {
+    if constexpr (IO16) {
+      *reinterpret_cast<uint2*>(d) = zero ? uint2{0u, 0u} : v;
+    } else if constexpr (NP == 3) {
       unsigned h0, m0, l0, h1, m1, l1;
       split3_pair(v.x, v.y, h0, m0, l0);
       split3_pair(v.z, v.w, h1, m1, l1);
@@ -312,6 +342,12 @@ __global__ __launch_bounds__(64 * PB) __attribute__((amdgpu_waves_per_eu(PP == 1
     // Q fragment: B operand, lane (query j, k-slots 8g .. 8g+7), scaled into the log2 domain
     u32x4 qb[NP];
     {
+      if constexpr (IO16) {   // bf16 q: unpack (the scale is applied in fp32, the product rounded to bf16 like the fp32 path's)
+        qreg[0] = float4{__uint_as_float(qraw[0] << 16), __uint_as_float(qraw[0] & 0xFFFF0000u), __uint_as_float(qraw[1] << 16),
+                         __uint_as_float(qraw[1] & 0xFFFF0000u)};
+        qreg[1] = float4{__uint_as_float(qraw[2] << 16), __uint_as_float(qraw[2] & 0xFFFF0000u), __uint_as_float(qraw[3] << 16),
+                         __uint_as_float(qraw[3] & 0xFFFF0000u)};
+      }
       const float f[8] = {qreg[0].x * G.qscale, qreg[0].y * G.qscale, qreg[0].z * G.qscale, qreg[0].w * G.qscale,
                           qreg[1].x * G.qscale, qreg[1].y * G.qscale, qreg[1].z * G.qscale, qreg[1].w * G.qscale};
 #pragma unroll
@@ -459,9 +495,16 @@ __global__ __launch_bounds__(64 * PB) __attribute__((amdgpu_waves_per_eu(PP == 1
     const float lsum = __shfl(oacc[2][0], j);
     const float inv = 1.0f / lsum;
     if (dest >= 0) {
-      float* o = out_b + dest * C + head * D + 4 * g;
-      *reinterpret_cast<f32x4*>(o) = oacc[0] * inv;
-      *reinterpret_cast<f32x4*>(o + 16) = oacc[1] * inv;
+      if constexpr (IO16) {
+        unsigned short* o = reinterpret_cast<unsigned short*>(out) + ((long long)b * L + dest) * C + head * D + 4 * g;
+        const f32x4 u0 = oacc[0] * inv, u1 = oacc[1] * inv;
+        *reinterpret_cast<uint2*>(o) = uint2{cvt_pk_bf16(u0[0], u0[1]), cvt_pk_bf16(u0[2], u0[3])};
+        *reinterpret_cast<uint2*>(o + 16) = uint2{cvt_pk_bf16(u1[0], u1[1]), cvt_pk_bf16(u1[2], u1[3])};
+      } else {
+        float* o = out_b + dest * C + head * D + 4 * g;
+        *reinterpret_cast<f32x4*>(o) = oacc[0] * inv;
+        *reinterpret_cast<f32x4*>(o + 16) = oacc[1] * inv;
+      }
     }
     __syncthreads();                                   // every wave is done with this window's LDS images
     ilon = inext;
@@ -553,7 +596,7 @@ static size_t lds_bytes(const Geo& G) {
   return (size_t)G.TRP * 4 + (size_t)NP * KR * LDK * 2 + (size_t)NP * VR * LDV * 2 + (size_t)2 * NS * 4;
 }
 
-template <int RP, int PP, int PB, int NP>
+template <int RP, int PP, int PB, int NP, bool IO16 = false>
 static int32_t launch3(const Geo& G, bool mask, const float* qkv, const float* qkv_bias, const float* tabT, float* out, int batch,
                        long long L, hipStream_t s) {
   const size_t lds = lds_bytes<RP, PP, PB, NP>(G);
@@ -570,10 +613,10 @@ static int32_t launch3(const Geo& G, bool mask, const float* qkv, const float* q
   };
   // (unshifted blocks run the same kernel: boundaries at 2^30, nothing cut, plane constants 0.  A mask-free instantiation
   // was no faster at NP = 1 and needed 9 spilled registers at NP = 3.)
-  int32_t rc = go(wattn3_kernel<RP, PP, PB, NP, 1>, grid);
+  int32_t rc = go(wattn3_kernel<RP, PP, PB, NP, 1, IO16>, grid);
   if (rc != DLWP_OK) return rc;
   if (mask && G.ncut > 0) {
-    rc = go(wattn3_kernel<RP, PP, PB, NP, 2>, dim3((unsigned)G.heads, (unsigned)gy2));
+    rc = go(wattn3_kernel<RP, PP, PB, NP, 2, IO16>, dim3((unsigned)G.heads, (unsigned)gy2));
     if (rc != DLWP_OK) return rc;
   }
   DLWP_HIP_CHECK(hipGetLastError());
@@ -587,6 +630,7 @@ size_t wattn3_workspace_bytes(const dlwp_wattn_desc* u, int /*batch*/, int /*np*
 }
 
 // 0 = done, 1 = not covered by this kernel (the caller falls through to the generic one), < 0 = error
+// np: 3 bf16x6 (fp32-accurate), 1 bf16, 16 bf16 with bfloat16 qkv / qkv bias / output tensors (the pointers are reinterpreted)
 int32_t wattn3_run(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_bias, const float* table, float* out, int batch,
                    void* workspace, size_t workspace_bytes, hipStream_t s, int np) {
   const Plan3 P = make_plan3(u);
@@ -611,7 +655,8 @@ int32_t wattn3_run(const dlwp_wattn_desc* u, const float* qkv, const float* qkv_
 #define DLWP_W3(RP_, PP_, PB_)                                                                                  \
   if (P.rp == RP_ && P.pp == PP_ && P.pb == PB_)                                                                \
     return np == 3 ? launch3<RP_, PP_, PB_, 3>(G, mask, qkv, qb, tabT, out, batch, L, s)                        \
-                   : launch3<RP_, PP_, PB_, 1>(G, mask, qkv, qb, tabT, out, batch, L, s);
+                   : (np == 16 ? launch3<RP_, PP_, PB_, 1, true>(G, mask, qkv, qb, tabT, out, batch, L, s)      \
+                               : launch3<RP_, PP_, PB_, 1>(G, mask, qkv, qb, tabT, out, batch, L, s));
   DLWP_W3(1, 1, 5) DLWP_W3(1, 1, 3) DLWP_W3(1, 1, 2) DLWP_W3(2, 0, 5) DLWP_W3(2, 0, 3) DLWP_W3(2, 0, 2) DLWP_W3(1, 0, 5)
   DLWP_W3(1, 0, 3) DLWP_W3(1, 0, 2)
 #undef DLWP_W3

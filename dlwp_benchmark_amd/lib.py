@@ -74,6 +74,8 @@ SIGNATURES = {
                                        c_size_t, c_void_p]),
     "dlwp_window_attn_bf16": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                         c_size_t, c_void_p]),
+    "dlwp_window_attn_bf16_io": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                           c_size_t, c_void_p]),
     "dlwp_window_attn_bwd_workspace_bytes": (c_size_t, [POINTER(WAttnDesc), c_int32]),
     "dlwp_window_attn_bwd_f32": (c_int32, [POINTER(WAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),

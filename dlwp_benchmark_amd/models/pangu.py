@@ -134,8 +134,12 @@ class _EarthSpecificBlock(nn.Module):
             prec = ops.form_precision(self.linear_form)
             if pend is not None:
                 x.add_(pend)
+            # all-bf16 form (bf16 Linear operands AND bf16 attention): qkv and the attention output cross HBM as bfloat16 too
+            # (dlwp_linear_bf16_io -> dlwp_window_attn_bf16_io -> dlwp_linear_bf16_io) where the fast attention kernels take the call
+            io16 = prec == "bf16" and self.attention_precision == "bf16" and ops.window_attention_io_supported(spec, x.shape[0])
             qkv = ops.linear(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps,
-                                            out_dtype=torch.bfloat16 if prec == "bf16" else None), self.attn.qkv, precision=prec)
+                                            out_dtype=torch.bfloat16 if prec == "bf16" else None), self.attn.qkv, precision=prec,
+                             out_dtype=torch.bfloat16 if io16 else None)
             a = ops.window_attention(qkv, self.attn.qkv.bias, self.attn.earth_position_bias_table, spec,
                                      precision=self.attention_precision)
             return ops.attention_block_tail(x, a, self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2, precision=prec), None

@@ -58,6 +58,11 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table:
     from . import training as _T
     if _T.wants_grad(qkv, qkv_bias, table) and not count_fallbacks:
         return _T.window_attention(qkv, qkv_bias, table, spec, precision)     # HIP forward, differentiable (training.py)
+    if qkv.dtype == torch.bfloat16:
+        # the hand-over of a block in the all-bf16 form: bf16 qkv in, bf16 attention output (dlwp_window_attn_bf16_io)
+        if precision != "bf16" or count_fallbacks:
+            raise _lib.DlwpError("window_attention: a bfloat16 qkv tensor goes with precision='bf16'")
+        return _window_attention_bf16_io(qkv, qkv_bias, table, spec)
     _lib.require_cuda_tensor(qkv, "qkv")
     _lib.require_cuda_tensor(table, "bias table")
     _lib.require_cuda_tensor(qkv_bias, "qkv bias")
@@ -88,6 +93,38 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table:
                 _lib.check(lib.dlwp_window_attn_fallbacks(ctypes.byref(d), b, 1 if bf16 else 0, ws.data_ptr(),
                                                           _lib.stream_ptr(), ctypes.byref(n)), "dlwp_window_attn_fallbacks")
             return out, int(n.value)
+    return out
+
+
+def window_attention_io_supported(spec: WindowSpec, batch: int) -> bool:
+    """True when dlwp_window_attn_bf16_io covers the descriptor (one of the two fast kernels takes it)."""
+    d = spec.to_c()
+    d.form = -1
+    return int(_lib.load().dlwp_window_attn_workspace_bytes(ctypes.byref(d), int(batch), 1)) > 0
+
+
+def _window_attention_bf16_io(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table: torch.Tensor, spec: WindowSpec):
+    if not qkv.is_cuda:
+        raise _lib.DlwpError("qkv must be a tensor on an MI355X device")
+    _lib.require_cuda_tensor(table, "bias table")
+    qkv, table = qkv.contiguous(), table.contiguous()
+    b, l, c3 = qkv.shape
+    c = spec.heads * spec.head_dim
+    if c3 != 3 * c or l != spec.grid[0] * spec.grid[1] * spec.grid[2]:
+        raise _lib.DlwpError(f"qkv shape {tuple(qkv.shape)} does not match grid {tuple(spec.grid)} x 3*{c}")
+    bias16 = qkv_bias.detach().to(torch.bfloat16).contiguous() if qkv_bias is not None else None
+    out = torch.empty(b, l, c, device=qkv.device, dtype=torch.bfloat16)
+    lib = _lib.load()
+    d = spec.to_c()
+    d.form = -1
+    with torch.cuda.device(qkv.device):
+        nbytes = int(lib.dlwp_window_attn_workspace_bytes(ctypes.byref(d), b, 1))
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=qkv.device)
+        rc = lib.dlwp_window_attn_bf16_io(ctypes.byref(d), qkv.data_ptr(), bias16.data_ptr() if bias16 is not None else None,
+                                          table.data_ptr(), out.data_ptr(), b, ws.data_ptr(), nbytes, _lib.stream_ptr())
+    if rc == -4:     # DLWP_ERR_UNSUPPORTED: a descriptor only the generic kernel takes -- the same arithmetic on fp32 tensors
+        return window_attention(qkv.float(), qkv_bias, table, spec, precision="bf16").to(torch.bfloat16)
+    _lib.check(rc, "dlwp_window_attn_bf16_io")
     return out
 
 

@@ -245,6 +245,14 @@ int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* desc, const float* qkv_dev,
                               const float* qkv_bias_dev, const float* table_dev, float* out_dev,
                               int32_t batch, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* dlwp_window_attn_bf16 with bfloat16 TENSORS: qkv_dev [B, L, 3 C], qkv_bias_dev [3 C] and out_dev [B, L, C] are bf16 -- the
+ * hand-over of a block in the bf16 form (the qkv Linear writes bf16, proj reads bf16: dlwp_linear_bf16_io).  Same arithmetic as
+ * dlwp_window_attn_bf16 on bf16-rounded inputs.  Covered: the descriptors of the two fast paths (workspace as for
+ * dlwp_window_attn_bf16); anything else returns DLWP_ERR_UNSUPPORTED (convert and call dlwp_window_attn_bf16). */
+int32_t dlwp_window_attn_bf16_io(const dlwp_wattn_desc* desc, const void* qkv_dev, const void* qkv_bias_dev,
+                                 const float* table_dev, void* out_dev, int32_t batch, void* workspace_dev,
+                                 size_t workspace_bytes, void* stream);
+
 /* Backward of dlwp_window_attn_f32 (csrc/window_attn_bwd.hip): what loss.backward() of reference scripts/train.py:263-271
  * runs through WindowAttention.forward (swin_transformer.py:122-154, :217-251) / EarthAttention3D.forward
  * (panguweather.py:176-211, :285-316), without their Linears.  Flash-style: scores are recomputed per 32 x 32 tile from

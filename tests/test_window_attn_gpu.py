@@ -153,3 +153,28 @@ def test_earth_window_kernel_large_logits():
     want = ops.window_attention(qkv, bias, table, spec, precision="fp32_mfma")
     got = ops.window_attention(qkv, bias, table, spec, precision="bf16x6")
     assert torch.isfinite(got).all() and rel_l2(got, want) <= 2e-4      # fp32 rounding of logits of several hundred
+
+
+@pytest.mark.parametrize("kind", ["swin", "swin_shifted", "pangu", "pangu_rolled"])
+def test_bf16_tensor_handover_is_bit_identical(kind):
+    """dlwp_window_attn_bf16_io (bf16 qkv in, bf16 out: the hand-over of a block in the all-bf16 form) computes exactly what
+    dlwp_window_attn_bf16 computes on the same bf16-representable values, rounded once more to bf16 on the way out."""
+    from dlwp_benchmark_amd import ops
+    from test_window_attn_bwd_gpu import _pangu_spec
+
+    if kind.startswith("swin"):
+        spec, rows = _spec(32, 64, 4, 24, kind.endswith("shifted"))
+        qkv, bias, table = _inputs(2, 32, 64, 4, 24, rows, seed=5)
+    else:
+        spec, tshape = _pangu_spec(24, 48, 4, 32, kind.endswith("rolled"))
+        g = torch.Generator().manual_seed(6)
+        qkv = torch.randn(2, 24 * 48, 3 * 4 * 32, generator=g).cuda()
+        bias = (0.3 * torch.randn(3 * 4 * 32, generator=g)).cuda()
+        table = (0.5 * torch.randn(*tshape, generator=g)).cuda()
+    assert ops.window_attention_io_supported(spec, 2)
+    q16 = qkv.to(torch.bfloat16)
+    b16 = bias.to(torch.bfloat16)
+    want = ops.window_attention(q16.float(), b16.float(), table, spec, precision="bf16")
+    got = ops.window_attention(q16, bias, table, spec, precision="bf16")
+    assert got.dtype == torch.bfloat16
+    assert torch.equal(got, want.to(torch.bfloat16))
