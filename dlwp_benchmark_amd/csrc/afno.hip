@@ -233,6 +233,166 @@ __global__ __launch_bounds__(256) void afno_mix_mfma16_kernel(const Params p) {
 
 using namespace dlwp;
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the mixing (training: loss.backward() of reference scripts/train.py:271 through fourcastnet.py:96-121).
+// Forward per kept point, with UNNORMALISED transforms around it:  xin = in_scale X,  o1 = relu(xin W1 + b1),
+// o2 = o1 W2 + b2,  Y = out_scale softshrink(o2),  y = C2R(Y).  Given G = R2C(grad_y) (the same forward transform):
+//   gz  = out_scale c_k G            (adjoint of the unnormalised C2R: c_k = 1 for the self-conjugate columns, 2 otherwise)
+//   d2  = gz  where |o2| > lambda    (softshrink)                 -> dW2 = sum_p conj(o1) (x) d2,  db2 = sum_p d2
+//   d1  = (d2 W2^H) where pre-activation > 0 (relu, re / im apart) -> dW1 = sum_p conj(xin) (x) d1, db1 = sum_p d1
+//   gX  = in_scale (d1 W1^H) / c_k   (adjoint of the unnormalised R2C is C2R of this)
+// The kernel recomputes the forward per point and writes gX plus the four per-point factors (xin, o1, d1, d2) of the weight
+// gradients, zeros outside the kept rows; the sums over the points are einsums on the caller's side (rocBLAS through torch,
+// like the spectral convolution's weight gradient).  One thread = one kept point, one block of BS channels at a time.
+// ---------------------------------------------------------------------------------------------------------------
+namespace dlwp {
+namespace afno {
+
+struct BwdParams {
+  const float2* x;    // [B][C][H][Wf]  R2C(x)
+  const float2* g;    // [B][C][H][Wf]  R2C(grad_y)
+  float2* gx;         // [B][C][H][Wf]  -> C2R gives grad_x
+  float2* xin;        // factors of the weight gradients, same layout
+  float2* o1;
+  float2* d1;
+  float2* d2;
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  int B, H, Wf, C, nb;
+  int row_lo, row_hi, km;
+  int nyq;            // column index of the Nyquist column (W / 2 for even W), or -1
+  float lambd, in_scale, out_scale;
+};
+
+template <int BS>
+__global__ __launch_bounds__(256) void afno_mix_bwd_kernel(const BwdParams p) {
+  const long long plane = (long long)p.H * p.Wf;
+  const long long npts = (long long)p.B * p.H * p.Wf;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npts; t += (long long)gridDim.x * blockDim.x) {
+    const int jcol = (int)(t % p.Wf);
+    const int h = (int)((t / p.Wf) % p.H);
+    const int b = (int)(t / ((long long)p.Wf * p.H));
+    const bool kept = h >= p.row_lo && h < p.row_hi && jcol < p.km;
+    const long long base = (long long)b * p.C * plane + (long long)h * p.Wf + jcol;
+    const float ck = (jcol == 0 || jcol == p.nyq) ? 1.0f : 2.0f;
+    for (int blk = 0; blk < p.nb; ++blk) {
+      float2 xin[BS], h1[BS], e2[BS], e1[BS], gxo[BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) { xin[i] = h1[i] = e2[i] = e1[i] = gxo[i] = float2{0.f, 0.f}; }
+      if (kept) {
+        const float* w1r = p.w1 + (long long)blk * BS * BS;
+        const float* w1i = w1r + (long long)p.nb * BS * BS;
+        const float* w2r = p.w2 + (long long)blk * BS * BS;
+        const float* w2i = w2r + (long long)p.nb * BS * BS;
+        bool m1r[BS], m1i[BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+          const float2 v = p.x[base + (long long)(blk * BS + i) * plane];
+          xin[i] = float2{v.x * p.in_scale, v.y * p.in_scale};
+        }
+#pragma unroll
+        for (int o = 0; o < BS; ++o) {
+          float ar = p.b1[blk * BS + o], ai = p.b1[p.nb * BS + blk * BS + o];
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const float r = w1r[i * BS + o], im = w1i[i * BS + o];
+            ar = fmaf(xin[i].x, r, fmaf(-xin[i].y, im, ar));
+            ai = fmaf(xin[i].y, r, fmaf(xin[i].x, im, ai));
+          }
+          m1r[o] = ar > 0.f;
+          m1i[o] = ai > 0.f;
+          h1[o] = float2{fmaxf(ar, 0.f), fmaxf(ai, 0.f)};
+        }
+#pragma unroll
+        for (int o = 0; o < BS; ++o) {
+          float ar = p.b2[blk * BS + o], ai = p.b2[p.nb * BS + blk * BS + o];
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const float r = w2r[i * BS + o], im = w2i[i * BS + o];
+            ar = fmaf(h1[i].x, r, fmaf(-h1[i].y, im, ar));
+            ai = fmaf(h1[i].y, r, fmaf(h1[i].x, im, ai));
+          }
+          const float2 gv = p.g[base + (long long)(blk * BS + o) * plane];
+          const float sc = p.out_scale * ck;
+          e2[o] = float2{fabsf(ar) > p.lambd ? gv.x * sc : 0.f, fabsf(ai) > p.lambd ? gv.y * sc : 0.f};
+        }
+        // d1 = d2 W2^H: o2r = h1r w2r - h1i w2i, o2i = h1i w2r + h1r w2i  ->  dh1r = d2r w2r + d2i w2i, dh1i = -d2r w2i + d2i w2r
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+          float ar = 0.f, ai = 0.f;
+#pragma unroll
+          for (int o = 0; o < BS; ++o) {
+            const float r = w2r[i * BS + o], im = w2i[i * BS + o];
+            ar = fmaf(e2[o].x, r, fmaf(e2[o].y, im, ar));
+            ai = fmaf(e2[o].y, r, fmaf(-e2[o].x, im, ai));
+          }
+          e1[i] = float2{m1r[i] ? ar : 0.f, m1i[i] ? ai : 0.f};
+        }
+        const float sx = p.in_scale / ck;
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+          float ar = 0.f, ai = 0.f;
+#pragma unroll
+          for (int o = 0; o < BS; ++o) {
+            const float r = w1r[i * BS + o], im = w1i[i * BS + o];
+            ar = fmaf(e1[o].x, r, fmaf(e1[o].y, im, ar));
+            ai = fmaf(e1[o].y, r, fmaf(-e1[o].x, im, ai));
+          }
+          gxo[i] = float2{ar * sx, ai * sx};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < BS; ++i) {
+        const long long o = base + (long long)(blk * BS + i) * plane;
+        p.gx[o] = gxo[i];
+        p.xin[o] = xin[i];
+        p.o1[o] = h1[i];
+        p.d1[o] = e1[i];
+        p.d2[o] = e2[i];
+      }
+    }
+  }
+}
+
+}  // namespace afno
+}  // namespace dlwp
+
+extern "C" int32_t dlwp_afno2d_mix_bwd_f32(const float* xf, const float* gf, float* gxf, float* xin, float* o1, float* d1, float* d2,
+                                           const float* w1, const float* b1, const float* w2, const float* b2, int32_t batch,
+                                           int32_t H, int32_t Wf, int32_t C, int32_t num_blocks, int32_t width,
+                                           float sparsity_threshold, float hard_thresholding_fraction, float in_scale,
+                                           float out_scale, void* stream) {
+  DLWP_REQUIRE(xf && gf && gxf && xin && o1 && d1 && d2 && w1 && b1 && w2 && b2, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0 && H > 0 && Wf > 0 && C > 0 && num_blocks > 0 && C % num_blocks == 0 && width > 0, DLWP_ERR_INVALID_ARGUMENT,
+               "bad shape");
+  afno::BwdParams p;
+  p.x = reinterpret_cast<const float2*>(xf); p.g = reinterpret_cast<const float2*>(gf);
+  p.gx = reinterpret_cast<float2*>(gxf); p.xin = reinterpret_cast<float2*>(xin); p.o1 = reinterpret_cast<float2*>(o1);
+  p.d1 = reinterpret_cast<float2*>(d1); p.d2 = reinterpret_cast<float2*>(d2);
+  p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2;
+  p.B = batch; p.H = H; p.Wf = Wf; p.C = C; p.nb = num_blocks;
+  const int bs = C / num_blocks;
+  const int total = H / 2 + 1;
+  const int kept = (int)((double)total * (double)hard_thresholding_fraction);
+  DLWP_REQUIRE(kept >= 1, DLWP_ERR_INVALID_ARGUMENT, "hard_thresholding_fraction keeps no mode");
+  p.row_lo = total - kept < 0 ? 0 : total - kept;
+  p.row_hi = total + kept > H ? H : total + kept;
+  p.km = kept > Wf ? Wf : kept;
+  p.nyq = (width % 2 == 0) ? width / 2 : -1;
+  p.lambd = sparsity_threshold; p.in_scale = in_scale; p.out_scale = out_scale;
+  const long long npts = (long long)batch * H * Wf;
+  long long blocks = (npts + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (bs) {
+    case 4: hipLaunchKernelGGL(afno::afno_mix_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 8: hipLaunchKernelGGL(afno::afno_mix_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 16: hipLaunchKernelGGL(afno::afno_mix_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    default: return fail(DLWP_ERR_UNSUPPORTED, "AFNO backward: block size %d not supported (4, 8, 16)", bs);
+  }
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
+
 extern "C" int32_t dlwp_afno2d_mix_scaled_f32(const float* xf, float* yf, const float* w1, const float* b1,
                                               const float* w2, const float* b2, int32_t batch, int32_t H, int32_t Wf,
                                               int32_t C, int32_t num_blocks, float sparsity_threshold,

@@ -694,7 +694,9 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const Params p) {
         u[b] = acc[a][b];
         v[b] = acc[a + 1][b];
         if (p.bias) { u[b] += bv[b]; v[b] += bv[b]; }
+#ifndef DLWP_KO_GELU
         if (p.act) gelu_erf8_fma(u[b], v[b]);
+#endif
         if constexpr (RES) {
           u[b] += rs[a][b];
           v[b] += rs[a + 1][b];

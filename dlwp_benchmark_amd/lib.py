@@ -83,6 +83,8 @@ SIGNATURES = {
                                       c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "dlwp_afno2d_mix_scaled_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                              c_int32, c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p]),
+    "dlwp_afno2d_mix_bwd_f32": (c_int32, [c_void_p] * 11 + [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
+                                          c_float, c_float, c_void_p]),
     "dlwp_fft2_plan_create": (c_int32, [ctypes.POINTER(c_void_p), c_int32, c_int32, c_int32]),
     "dlwp_fft2_plan_destroy": (c_int32, [c_void_p]),
     "dlwp_rfft2_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),

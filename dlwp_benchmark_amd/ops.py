@@ -487,6 +487,46 @@ def afno_kept_cols(h: int, w: int, hard_thresholding_fraction: float) -> int:
     return max(0, min(int((h // 2 + 1) * hard_thresholding_fraction), w // 2 + 1))
 
 
+def afno2d_filter_backward(x_cf: torch.Tensor, grad_y: torch.Tensor, w1, b1, w2, b2, num_blocks: int,
+                           sparsity_threshold: float, hard_thresholding_fraction: float):
+    """Gradients of afno2d_filter_cf with respect to (x_cf, w1, b1, w2, b2), or None when the grid is not one of the
+    hand-written kept-column transforms / the block size is not 4, 8 or 16 (the caller then differentiates the torch form).
+    grad_x = C2R(mix_bwd(R2C(x), R2C(grad_y))): the same two hand-written transforms as the forward around
+    dlwp_afno2d_mix_bwd_f32 (which recomputes the per-point MLP); the weight gradients are sums over the spectrum points of
+    per-point factors the kernel writes -- four complex einsums (reference backward: train.py:271 through fourcastnet.py:85-124)."""
+    _lib.require_cuda_tensor(x_cf, "x_cf")
+    _lib.require_cuda_tensor(grad_y, "grad_y")
+    x_cf, grad_y = x_cf.contiguous(), grad_y.contiguous()
+    b, c, h, w = x_cf.shape
+    lib = _lib.load()
+    kc = afno_kept_cols(h, w, hard_thresholding_fraction)
+    bs = c // num_blocks
+    if kc < 1 or not lib.dlwp_afno_fft_supported(h, w, kc) or bs not in (4, 8, 16):
+        return None
+    scale = 1.0 / float(h * w) ** 0.5
+    with torch.cuda.device(x_cf.device):
+        st = _lib.stream_ptr()
+        plan = _afno_fft_plans.get(x_cf.device, h, w, kc)
+        mk = lambda: torch.empty(b, c, h, kc, 2, device=x_cf.device, dtype=torch.float32)
+        xf, gf, gxf, xin, o1, d1, d2 = mk(), mk(), mk(), mk(), mk(), mk(), mk()
+        _lib.check(lib.dlwp_afno_rfft2_kept_f32(plan, x_cf.data_ptr(), xf.data_ptr(), b * c, st), "dlwp_afno_rfft2_kept_f32")
+        _lib.check(lib.dlwp_afno_rfft2_kept_f32(plan, grad_y.data_ptr(), gf.data_ptr(), b * c, st), "dlwp_afno_rfft2_kept_f32")
+        ptr = lambda t: t.detach().contiguous().data_ptr()
+        _lib.check(lib.dlwp_afno2d_mix_bwd_f32(xf.data_ptr(), gf.data_ptr(), gxf.data_ptr(), xin.data_ptr(), o1.data_ptr(),
+                                               d1.data_ptr(), d2.data_ptr(), ptr(w1), ptr(b1), ptr(w2), ptr(b2), b, h, kc, c,
+                                               num_blocks, w, float(sparsity_threshold), float(hard_thresholding_fraction),
+                                               scale, scale, st), "dlwp_afno2d_mix_bwd_f32")
+        gx = torch.empty_like(x_cf)
+        _lib.check(lib.dlwp_afno_irfft2_kept_f32(plan, gxf.data_ptr(), gx.data_ptr(), b * c, st), "dlwp_afno_irfft2_kept_f32")
+    cv = lambda t: torch.view_as_complex(t).view(b, num_blocks, bs, h, kc)
+    gw1 = torch.einsum("bnihk,bnohk->nio", cv(xin).conj(), cv(d1))
+    gw2 = torch.einsum("bnihk,bnohk->nio", cv(o1).conj(), cv(d2))
+    gb1 = cv(d1).sum(dim=(0, 3, 4))
+    gb2 = cv(d2).sum(dim=(0, 3, 4))
+    ri = lambda t: torch.stack([t.real, t.imag], dim=0).contiguous()       # reference layout [2, nb, bs(, bs)]
+    return gx, ri(gw1), ri(gb1), ri(gw2), ri(gb2)
+
+
 def afno2d_filter_cf(x_cf: torch.Tensor, w1, b1, w2, b2, num_blocks: int, sparsity_threshold: float,
                      hard_thresholding_fraction: float, use_rocfft: bool = False) -> torch.Tensor:
     """irfft2(mix(rfft2(x_cf, norm="ortho")), norm="ortho") for CHANNELS-FIRST x_cf [B, C, H, W]

@@ -323,7 +323,15 @@ class _AfnoFilterFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        """HIP backward (ops.afno2d_filter_backward: the hand-written transforms around dlwp_afno2d_mix_bwd_f32); grids / block
+        sizes it does not take and DLWP_TRAIN_TORCH_BACKWARD=1 differentiate the torch form below."""
+        from . import ops
+
         saved = ctx.saved_tensors
+        if not _TORCH_BACKWARD():
+            res = ops.afno2d_filter_backward(saved[0], grad_out, saved[1], saved[2], saved[3], saved[4], *ctx.cfg)
+            if res is not None:
+                return (*[g if need else None for g, need in zip(res, ctx.needs_input_grad[:5])], None, None, None)
         with torch.enable_grad():
             ins = [t.detach().requires_grad_(need) for t, need in zip(saved, ctx.needs_input_grad[:5])]
             out = afno_filter_torch(*ins, *ctx.cfg)
@@ -378,9 +386,45 @@ class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         from . import healpix as _hpx
+        from . import ops
 
         pre_act, act, hpx = ctx.cfg
         saved = ctx.saved_tensors
+        if not hpx and not _TORCH_BACKWARD():
+            # CylinderPad (circular in longitude, zeros in latitude) + 3x3: the input gradient is the SAME operator with the weights
+            # transposed and flipped -- dlwp_conv3x3_ex_f32 again (reference backward: train.py:271 through unet.py:429-555,
+            # convlstm.py:82-111); pre- / post-activation derivatives are pointwise torch operators, the weight gradient is one
+            # correlation of the padded input with the output gradient (MIOpen through torch, like the other weight gradients)
+            x0, x1, weight, bias, resid = saved
+            with torch.no_grad():
+                xcat = x0 if x1 is None else torch.cat([x0, x1], dim=1)
+                gz = grad_out.contiguous()
+                if act != 0:
+                    z = ops.conv3x3(x0, weight, bias, act=0, x1=x1, pre_act=pre_act, resid=resid)
+                    with torch.enable_grad():
+                        z_ = z.detach().requires_grad_(True)
+                        gz, = torch.autograd.grad(_ACT_FNS[act](z_), z_, gz)
+                    gz = gz.contiguous()
+                res = [None] * 5
+                if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+                    wt = weight.flip(2, 3).transpose(0, 1).contiguous()
+                    dxa = ops.conv3x3(gz, wt, None)
+                    if pre_act != 0:
+                        with torch.enable_grad():
+                            xc_ = xcat.detach().requires_grad_(True)
+                            dxa, = torch.autograd.grad(_ACT_FNS[pre_act](xc_), xc_, dxa)
+                    c0 = x0.shape[1]
+                    res[0] = dxa[:, :c0].contiguous() if ctx.needs_input_grad[0] else None
+                    res[1] = dxa[:, c0:].contiguous() if (x1 is not None and ctx.needs_input_grad[1]) else None
+                if ctx.needs_input_grad[2]:
+                    xa = _ACT_FNS[pre_act](xcat)
+                    xp = F.pad(F.pad(xa, (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1))
+                    res[2] = torch.nn.grad.conv2d_weight(xp, weight.shape, gz)
+                if bias is not None and ctx.needs_input_grad[3]:
+                    res[3] = gz.sum(dim=(0, 2, 3))
+                if resid is not None and ctx.needs_input_grad[4]:
+                    res[4] = gz
+            return (*res, None, None, None)
         with torch.enable_grad():
             ins = [t.detach().requires_grad_(need) if t is not None else None for t, need in zip(saved, ctx.needs_input_grad[:5])]
             table = _hpx.device_table(ins[0].shape[2], ins[0].shape[3], 1, ins[0].device) if hpx else None

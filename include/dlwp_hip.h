@@ -281,6 +281,16 @@ int32_t dlwp_afno2d_mix_f32(const float* xf_dev, float* yf_dev, const float* w1_
                             const float* w2_dev, const float* b2_dev, int32_t batch, int32_t height,
                             int32_t wf, int32_t channels, int32_t num_blocks, float sparsity_threshold,
                             float hard_thresholding_fraction, void* stream);
+/* Backward of the mixing between UNNORMALISED transforms (training; fourcastnet.py:96-121 under loss.backward()):
+ * xf = R2C(x), gf = R2C(grad_y), both [B, C, H, Wf, 2] as above (Wf = the columns the transforms carry; `width` = W of the
+ * real field, for the Hermitian weight of the Nyquist column).  Writes gxf (its C2R is grad_x) and the per-point factors of the
+ * weight gradients -- xin, o1 (post-ReLU), d1, d2 (masked upstream gradients), same layout, zeros outside the kept modes:
+ * dW1 = sum_p conj(xin) (x) d1, db1 = sum_p d1, dW2 = sum_p conj(o1) (x) d2, db2 = sum_p d2 per block (csrc/afno.hip). */
+int32_t dlwp_afno2d_mix_bwd_f32(const float* xf_dev, const float* gf_dev, float* gxf_dev, float* xin_dev, float* o1_dev,
+                                float* d1_dev, float* d2_dev, const float* w1_dev, const float* b1_dev, const float* w2_dev,
+                                const float* b2_dev, int32_t batch, int32_t height, int32_t wf, int32_t channels,
+                                int32_t num_blocks, int32_t width, float sparsity_threshold, float hard_thresholding_fraction,
+                                float in_scale, float out_scale, void* stream);
 /* Same with yf = out_scale * mix(in_scale * xf): lets the caller use UNNORMALISED transforms (below) and still get
  * the reference's norm="ortho" arithmetic (:87, :122; in_scale = out_scale = 1/sqrt(H*W)) without two elementwise
  * passes over the spectrum.  yf_dev may be xf_dev (in place): a point's channels are read before they are written and

@@ -126,3 +126,24 @@ def test_linear_training_function_matches_autograd():
     gx, gw, gb = torch.autograd.grad((y2 * r.double()).sum(), [x, m.weight, m.bias])
     assert rel_l2(y, y2) <= 1e-6
     assert rel_l2(got[0], gx) <= 2e-6 and rel_l2(got[1], gw) <= 2e-6 and rel_l2(got[2], gb) <= 2e-6
+
+
+@pytest.mark.parametrize("h,w,c,nb,frac", [(32, 64, 16, 4, 1.0), (128, 256, 64, 4, 1.0), (32, 64, 32, 2, 0.5)])
+def test_afno_filter_backward_matches_autograd(h, w, c, nb, frac):
+    """ops.afno2d_filter_backward (hand-written kept-column transforms + dlwp_afno2d_mix_bwd_f32 + four einsums) against autograd
+    of training.afno_filter_torch (fourcastnet.py:85-124 in torch operators)."""
+    from dlwp_benchmark_amd import ops, training as T
+
+    g = torch.Generator().manual_seed(h + c)
+    bs = c // nb
+    x = torch.randn(2, c, h, w, generator=g).to(DEV)
+    w1, w2 = [(0.3 * torch.randn(2, nb, bs, bs, generator=g)).to(DEV) for _ in range(2)]
+    b1, b2 = [(0.3 * torch.randn(2, nb, bs, generator=g)).to(DEV) for _ in range(2)]
+    gy = torch.randn(2, c, h, w, generator=g).to(DEV)
+    ins = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    out = T.afno_filter_torch(*ins, nb, 0.01, frac)
+    want = torch.autograd.grad(out, ins, gy)
+    got = ops.afno2d_filter_backward(x, gy, w1, b1, w2, b2, nb, 0.01, frac)
+    assert got is not None, "grid should be covered by the hand-written transforms"
+    for name, a, b in zip(("dx", "dw1", "db1", "dw2", "db2"), got, want):
+        assert rel_l2(a, b) <= 2e-5, (name, rel_l2(a, b))

@@ -4,7 +4,7 @@
 set -e
 out=gpurun_out/$1
 mkdir -p $out
-timeout -k 10 200 python bench.py --cpu-batch 1 --no-other-configs > $out/bench.json 2> $out/bench.err
+timeout -k 10 200 python bench.py --cpu-batch 1 --no-other-configs --no-second-form --detail $out/bench_detail.json > $out/bench.json 2> $out/bench.err
 python - <<PY
 import json
 d=json.load(open("$out/bench.json"))
