@@ -910,8 +910,12 @@ static int32_t launch(const Params& p, int form, hipStream_t s) {
   static const bool ring = !(getenv("DLWP_LINEAR_RING") && atoi(getenv("DLWP_LINEAR_RING")) == 0);      // A/B: 0 = the register-staged kernel for bf16 x as well
   // the ring kernel where its 256-row tiles fill the chip several times over (one 512-thread workgroup per CU); smaller calls
   // (Swin stage 1: 16 384 rows) keep linear_kernel's 128-row tiles at two workgroups per CU
+  static const long long ring_min = getenv("DLWP_LINEAR_RING_MIN_TILES") ? atoll(getenv("DLWP_LINEAR_RING_MIN_TILES")) : 1024;
   const long long ring_tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-  if (ring && (form == 4 || form == 6) && p.K % 64 == 0 && p.K >= 3 * 64 && (form == 4 || p.N % 8 == 0) && ring_tiles >= 1024) {
+  // (between 512 and 1024 tiles -- two or three rounds of the chip -- the ring pays only where the k loop is long: Pangu layers 2 / 3,
+  // 65 536 rows: fc2 (K = 1 536 -> 384) 147 -> 125 us, the output projection (K = 384 -> 384) 55 -> 58; profiles/r03_linear_ring_tiles.txt)
+  const bool ring_fill = ring_tiles >= ring_min || (2 * ring_tiles >= ring_min && p.K >= 768);
+  if (ring && (form == 4 || form == 6) && p.K % 64 == 0 && p.K >= 3 * 64 && (form == 4 || p.N % 8 == 0) && ring_fill) {
     const bool narrow_r = (p.N % 128) != 0 && (p.N % 128) <= 96 && (p.N % 96 == 0 || p.N < 128);
     constexpr int S = DLWP_LIN_RING_STAGES;
 #define DLWP_RING(BN_, OB_) (p.resid ? launch_ring<BN_, OB_, S, true>(p, s) : launch_ring<BN_, OB_, S, false>(p, s))

@@ -55,6 +55,9 @@ struct Images {           // device pointers into the caller's workspace
   int* dest;               // [nwin][N]     output token of window position n after the backward roll
   int* fallbacks;          // [1]           workgroups that left the exponent slack and redid their loop exactly (this call)
   float* kmax2;            // [rows * cq / 64]  per prep wave: max |k|^2 of its 64 / cq consecutive K rows
+                           // (DIRECT: [groups], one maximum per (b, head, window), from wattn2_kmax_kernel)
+  const unsigned short* qkv16;   // DIRECT: the bfloat16 qkv tensor [B][L][3 C] itself -- no operand images, no prep kernel
+  const float* table;            // DIRECT: the relative-position bias table [TR][heads] as the caller holds it
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return (unsigned short)(cvt_pk_bf16(x, 0.f) & 0xFFFFu); }
@@ -168,6 +171,43 @@ __global__ __launch_bounds__(256) void wattn2_prep_kernel(const Geo G, const flo
   }
 }
 
+// DIRECT form, shifted blocks only: max |k|^2 over the keys of every (b, head, window) group, straight from the bf16 qkv tensor
+// (12 MB at Swin stage 0 against the 50 MB of images the prep kernel writes).  grid = (groups, N / 256), one key per thread with
+// all of its loads in flight at once; block (group, y) leaves its partial maximum in kmax2[group * (N / 256) + y] (the attention
+// kernel reduces the N / 256 partials of its group).  Block (0, 0) also resets the call's fallback counter.
+__global__ __launch_bounds__(256) void wattn2_kmax_kernel(const Geo G, Images I) {
+  __shared__ float s_m[4];
+  const int group = blockIdx.x;
+  if (group == 0 && blockIdx.y == 0 && threadIdx.x == 0) *I.fallbacks = 0;
+  const int win = group % G.nwin, head = (group / G.nwin) % G.heads, b = group / (G.nwin * G.heads);
+  const int ilat = win / G.nlon, ilon = win % G.nlon;
+  const long long L = (long long)G.lat * G.lon;
+  const int n = blockIdx.y * 256 + threadIdx.x;          // N is a multiple of 64 (make_plan), the grid covers it in 256s
+  float n2 = 0.f;
+  if (n < G.N) {
+    int sa = ilat * G.wlat + n / G.wlon + G.sf[0], so = ilon * G.wlon + n % G.wlon + G.sf[1];
+    sa -= sa >= G.lat ? G.lat : 0;
+    so -= so >= G.lon ? G.lon : 0;
+    const unsigned short* src = I.qkv16 + ((long long)b * L + (long long)sa * G.lon + so) * 3 * G.C + G.C + head * G.d;
+    u32x4 raw[6];                                        // head_dim <= 48 (make_plan)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) raw[c] = 8 * c < G.d ? *reinterpret_cast<const u32x4*>(src + 8 * c) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(raw[c][i] << 16), hi = __uint_as_float(raw[c][i] & 0xFFFF0000u);
+        n2 += lo * lo + hi * hi;
+      }
+  }
+  float m = n2;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) I.kmax2[(long long)group * gridDim.y + blockIdx.y] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // attention
 //   DK  k-steps of 32 over the padded head dimension (DKP = 32 DK > d: the spare slot d carries -m~ / ones)
@@ -178,9 +218,13 @@ __global__ __launch_bounds__(256) void wattn2_prep_kernel(const Geo G, const flo
 __device__ constexpr int kTA[6] = {2, 0, 1, 1, 0, 0};   // bf16x6 terms, smallest first: (A part, B part)
 __device__ constexpr int kTB[6] = {0, 2, 1, 0, 1, 0};
 
-template <int D8, int SUB, int NP, bool MASK>
+//   DIRECT (NP = 1 with bfloat16 tensors, round 3): Q, K and V are gathered from the qkv tensor the block's qkv Linear wrote --
+//   the window order (roll included) through an LDS token map, the spare-slot constants formed in registers, the bias slice
+//   from the caller's table -- so that no prep kernel and no operand images exist (20 us per Swin stage-0 block, 50 MB)
+template <int D8, int SUB, int NP, bool MASK, bool DIRECT = false>
 __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo G, const Images I, float* __restrict__ out,
                                                                        int groups, int nqb, int rev_floats) {
+  static_assert(!DIRECT || NP == 1, "the direct form reads bf16 tensors: one part per operand");
   extern __shared__ __align__(16) float smem[];
   constexpr int KT = 32;
   constexpr int d = 8 * D8;                                         // head dimension (compile time)
@@ -222,9 +266,52 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
   int* s_flag = reinterpret_cast<int*>(s_tiles + 2 * TILE_F);        // [4]: redo vote, number of needed tiles
   int4* s_tinfo = reinterpret_cast<int4*>(s_flag + 4);               // [ntile] {bias term block 0, block 1, regions, tile}
   int* s_list = reinterpret_cast<int*>(s_tinfo + ntile);             // [ntile] needed tiles of this workgroup, in order
+  int* s_src = s_list + ntile;                                       // DIRECT: [N] qkv row offset of window position n (forward roll applied)
+  // DIRECT: [64 SUB] output token of the workgroup's queries, behind everything the epilogue's O tile overlays (launch(): lds)
+  int* s_dst;
+  {
+    const int loop_f = rev_floats + 2 * TILE_F + 4 + 4 * ntile + ntile + N, epi_f = 64 * SUB * (16 * ((8 * D8 + 15) / 16) + 1);
+    s_dst = reinterpret_cast<int*>(smem) + (loop_f > epi_f ? loop_f : epi_f);
+  }
+  if constexpr (DIRECT) {
+    const float LOG2E = 1.4426950408889634f;
+    // eight loads in flight per thread (a load-then-store loop would pay one L2 round trip per element: ~17 in a row at Swin stage 0)
+    for (int i0 = tid; i0 < rev_floats; i0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int x = rev_lo + i0 + 256 * u;
+        v[u] = (i0 + 256 * u < rev_floats && x < G.TR) ? I.table[(long long)(G.TR - 1 - x) * G.heads + head] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 256 * u < rev_floats) s_rev[i0 + 256 * u] = v[u] * LOG2E;
+    }
+    // token (times the row length 3 C of the qkv tensor) of window position n, forward roll applied; one division per thread,
+    // then n += 256 as (zlat, zlon) += (256 / wlon, 256 % wlon) with a carry
+    const int step_lat = 256 / G.wlon, step_lon = 256 % G.wlon;
+    int zlat = tid / G.wlon, zlon = tid % G.wlon;
+    for (int n = tid; n < N; n += 256) {
+      int sa = ilat * G.wlat + zlat + G.sf[0], so = ilon * G.wlon + zlon + G.sf[1];
+      sa -= sa >= G.lat ? G.lat : 0;
+      so -= so >= G.lon ? G.lon : 0;
+      s_src[n] = (sa * G.lon + so) * (3 * G.C);
+      zlon += step_lon;
+      zlat += step_lat + (zlon >= G.wlon ? 1 : 0);
+      zlon -= zlon >= G.wlon ? G.wlon : 0;
+    }
+    if (tid < 64 * SUB) {   // output token of the workgroup's query positions: out[(p + sb) mod dim] = attn_shifted[p]
+      const int qn = qblk * (64 * SUB) + tid;
+      int da = ilat * G.wlat + qn / G.wlon + G.sb[0], dq = ilon * G.wlon + qn % G.wlon + G.sb[1];
+      da -= da >= G.lat ? G.lat : 0;
+      dq -= dq >= G.lon ? G.lon : 0;
+      s_dst[tid] = da * G.lon + dq;
+    }
+  } else {
   for (int i = tid; i < rev_floats / 4; i += 256)
     if (rev_lo + 4 * i < TRP)
       reinterpret_cast<float4*>(s_rev)[i] = reinterpret_cast<const float4*>(I.rev + (long long)head * TRP + rev_lo)[i];
+  }
   auto region_of = [&](int n0) {   // region id of the 16 consecutive window positions starting at n0 (one latitude row)
     const int A = ilat * G.wlat + n0 / G.wlon, O = ilon * G.wlon + n0 % G.wlon;
     return ((A >= G.b1[0]) + (A >= G.b2[0])) * 3 + (O >= G.b1[1]) + (O >= G.b2[1]);
@@ -253,6 +340,7 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
   }
 
   const long long img_row0 = (long long)group * N;   // images are indexed [(b, head, win)][n]: group IS that index
+  const unsigned short* qkv_b = DIRECT ? I.qkv16 + (long long)(group / (G.nwin * G.heads)) * G.lat * G.lon * (3 * G.C) : nullptr;
   // 16-query chunk c of the workgroup's block goes to (wave c % 4, sub c / 4): a wave's sub-tiles are 64 positions apart,
   // i.e. in the same longitude band on consecutive latitude rows when the window is 64 wide -> usually ONE region
   auto chunk_q0 = [&](int sub) { return qblk * (64 * SUB) + 16 * (4 * sub + wave); };
@@ -267,8 +355,21 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
 #pragma unroll
     for (int ks = 0; ks < DK; ++ks)
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
-        qb[sub][ks][p] = *reinterpret_cast<const u32x4*>(I.q[p] + (img_row0 + qn) * DKP + 32 * ks + 8 * g);
+      for (int p = 0; p < NP; ++p) {
+        if constexpr (DIRECT) {
+          // q * (scale log2 e), rounded to bf16 again: what the prep kernel writes for a bfloat16 qkv tensor
+          u32x4 qv = {0u, 0u, 0u, 0u};
+          if (32 * ks + 8 * g < d) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qkv_b + (unsigned)(s_src[qn] + head * d + 32 * ks + 8 * g));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              qv[i] = cvt_pk_bf16(__uint_as_float(raw[i] << 16) * G.qscale, __uint_as_float(raw[i] & 0xFFFF0000u) * G.qscale);
+          }
+          qb[sub][ks][p] = qv;
+        } else {
+          qb[sub][ks][p] = *reinterpret_cast<const u32x4*>(I.q[p] + (img_row0 + qn) * DKP + 32 * ks + 8 * g);
+        }
+      }
     const int qlat = qn / G.wlon, qlon = qn % G.wlon;
     aq[sub] = G.TR - 1 - (qlat + G.wlat - 1) * G.W2 - (qlon + G.wlon - 1) + 4 * g - rev_lo;
     qreg[sub] = MASK ? region_of(q0) : 0;
@@ -287,6 +388,10 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
     // max |k|^2 over the window's keys: the prep kernel left one partial maximum per 64 / (DKP / 8) rows
     constexpr int RPW = 64 / (DKP / 8);
     float km = 0.f;
+    if constexpr (DIRECT) {
+      const int nb = (N + 255) / 256;
+      for (int i = tid; i < nb; i += 256) km = fmaxf(km, I.kmax2[(long long)group * nb + i]);
+    } else
     for (int i = tid; i < N / RPW; i += 256) km = fmaxf(km, I.kmax2[(long long)group * (N / RPW) + i]);
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) km = fmaxf(km, __shfl_xor(km, m));
@@ -319,12 +424,33 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
   constexpr int ITEMS = NP * KT * (CK + CV);
   constexpr int NI = (ITEMS + 255) / 256;
   u32x4 stg[NI];
+  // DIRECT: what this thread stages, fixed for the kernel -- key row in the tile and element offset in the qkv row
+  // (>= 0: 16 bytes of K / V; -1: the chunk with the column of ones; -2: zeros)
+  int d_row[NI], d_off[NI];
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int i = tid + it * 256;
+    const bool isk = i < KT * CK;
+    const int iv = isk ? i : i - KT * CK;
+    const int c = isk ? iv % CK : iv % CV;
+    d_row[it] = isk ? iv / CK : iv / CV;
+    d_off[it] = 8 * c < d ? (isk ? 1 : 2) * G.C + head * d + 8 * c : (8 * c == d ? -1 : -2);
+  }
   auto stage_load = [&](int kt) {
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
       const int i = tid + it * 256;
       if (i < ITEMS) {
         const int p = i / (KT * (CK + CV)), ii = i % (KT * (CK + CV));
+        if constexpr (DIRECT) {
+          // chunk c of key kt KT + r: head dims 8c .. 8c+7 of K / V where they exist, the column of ones in slot d, zeros beyond
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (d_off[it] >= 0) v = *reinterpret_cast<const u32x4*>(qkv_b + (unsigned)(s_src[kt * KT + d_row[it]] + d_off[it]));
+          else if (d_off[it] == -1) v[0] = 0x3F80u;   // bf16 1.0 in the low half
+          stg[it] = v;
+          (void)p; (void)ii;
+          continue;
+        }
         const long long row0 = img_row0 + (long long)kt * KT;
         if (ii < KT * CK) stg[it] = *reinterpret_cast<const u32x4*>(I.k[p] + (row0 + ii / CK) * DKP + 8 * (ii % CK));
         else {
@@ -614,7 +740,7 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
   if (s_flag[0]) {
     // exact fallback (workgroup-uniform, counted): every key block (masked ones with -100), the exact maximum of every
     // query from a max-only pass, then the pass again
-    if (tid == 0) atomicAdd(I.fallbacks, 1);
+    if (tid == 0 && (!DIRECT || MASK)) atomicAdd(I.fallbacks, 1);
     if (MASK) {
       exact_mask = true;
       if (tid == 0) {
@@ -655,7 +781,12 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
   for (int i = tid; i < 64 * SUB * d4; i += 256) {
     const int ql = i / d4, e = 4 * (i % d4);
     const int qn = qblk * (64 * SUB) + ql;
-    const int dst = I.dest[win * N + qn];
+    int dst;
+    if constexpr (DIRECT) {
+      dst = s_dst[ql];
+    } else {
+      dst = I.dest[win * N + qn];
+    }
     const float* so = s_o + ql * LDO + e;
     if (G.io16) {
       unsigned short* o16 = reinterpret_cast<unsigned short*>(out) + ((long long)b * G.lat * G.lon + dst) * G.C + head * d + e;
@@ -724,7 +855,7 @@ static Plan make_plan(const dlwp_wattn_desc* u, int batch, int np) {
   return P;
 }
 
-template <int D8, int SUB, int NP>
+template <int D8, int SUB, int NP, bool DIRECT = false>
 static int32_t launch(const Plan& P, const Images& I, float* out, int batch, hipStream_t s) {
   constexpr int KT = 32, DK = (8 * D8) / 32 + 1, DB = (8 * D8 + 15) / 16, DKP = 32 * DK, DVP = 16 * DB, LDK = DKP + 16,
                 LDV = DVP == 16 ? 16 : (DVP <= 48 ? 48 : 80);
@@ -733,14 +864,14 @@ static int32_t launch(const Plan& P, const Images& I, float* out, int batch, hip
   // slice of the reversed bias column a workgroup keeps in LDS: (wlat + rows of its query block - 1) table rows (+ alignment)
   const int nq_rows = (64 * SUB + P.G.wlon - 1) / P.G.wlon;
   const int rev_floats = (((P.G.wlat + nq_rows - 1) * P.G.W2 + 3 + 3) & ~3) + 4;
-  const size_t loop_f = (size_t)rev_floats + 2 * TILE_F + 4 + 4 * ntile + ntile;
+  const size_t loop_f = (size_t)rev_floats + 2 * TILE_F + 4 + 4 * ntile + ntile + (DIRECT ? (size_t)P.G.N : 0);
   const size_t epi_f = (size_t)64 * SUB * (DVP + 1);
-  const size_t lds = (loop_f > epi_f ? loop_f : epi_f) * 4;
+  const size_t lds = (loop_f > epi_f ? loop_f : epi_f) * 4 + (DIRECT ? 64 * SUB * 4 : 0);
   DLWP_REQUIRE(lds <= 160 * 1024, DLWP_ERR_UNSUPPORTED, "window attention needs %zu bytes of LDS (bias table too large)", lds);
   const int groups = batch * P.G.heads * P.G.nwin;
   const int nqb = P.G.N / (64 * SUB);
   const int grid = ((groups + 7) / 8) * 8 * nqb;
-  auto kern = P.G.use_mask ? wattn2_kernel<D8, SUB, NP, true> : wattn2_kernel<D8, SUB, NP, false>;
+  auto kern = P.G.use_mask ? wattn2_kernel<D8, SUB, NP, true, DIRECT> : wattn2_kernel<D8, SUB, NP, false, DIRECT>;
   if (lds > 48 * 1024)
     DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, P.G, I, out, groups, nqb, rev_floats);
@@ -764,6 +895,33 @@ static int32_t run_np(const Plan& P_in, const float* qkv, const float* table, fl
   I.dest = reinterpret_cast<int*>(w + P.off_dest);
   I.fallbacks = reinterpret_cast<int*>(w + P.off_fb);
   I.kmax2 = reinterpret_cast<float*>(w + P.off_kmax);
+  if constexpr (NP == 1) {
+    // bfloat16 tensors: the attention kernel gathers its operands itself (DLWP_WATTN2_DIRECT=0, read once: the prep kernel + images, A/B)
+    static const bool direct = !(getenv("DLWP_WATTN2_DIRECT") && atoi(getenv("DLWP_WATTN2_DIRECT")) == 0);
+    if (io16 && direct) {
+      I.qkv16 = reinterpret_cast<const unsigned short*>(qkv);
+      I.table = table;
+      const int groups = batch * P.G.heads * P.G.nwin;
+      // shifted blocks: the key-norm pass (it also resets the fallback counter).  Plain blocks launch nothing in front of the attention
+      // kernel: their counter is NOT maintained (dlwp_window_attn_fallbacks describes the fp32-tensor entry points; include/dlwp_hip.h)
+      if (P.G.use_mask) {
+        hipLaunchKernelGGL(wattn2_kmax_kernel, dim3((unsigned)groups, (unsigned)((P.G.N + 255) / 256)), dim3(256), 0, s, P.G, I);
+        DLWP_HIP_CHECK(hipGetLastError());
+      }
+#define DLWP_W2D(D8_)                                                         \
+  do {                                                                        \
+    if (P.SUB == 4) return launch<D8_, 4, 1, true>(P, I, out, batch, s);      \
+    if (P.SUB == 2) return launch<D8_, 2, 1, true>(P, I, out, batch, s);      \
+    return launch<D8_, 1, 1, true>(P, I, out, batch, s);                      \
+  } while (0)
+      if (P.G.d == 8) DLWP_W2D(1);
+      if (P.G.d == 16) DLWP_W2D(2);
+      if (P.G.d == 24) DLWP_W2D(3);
+      if (P.G.d == 48) DLWP_W2D(6);
+#undef DLWP_W2D
+      return fail(DLWP_ERR_UNSUPPORTED, "window attention fast path: head_dim %d not instantiated", P.G.d);
+    }
+  }
   const long long chunks = (long long)batch * P.G.heads * P.G.nwin * P.G.N * (2 * P.DKP / 8 + P.DVP / 8);
   long long blocks = (chunks + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;

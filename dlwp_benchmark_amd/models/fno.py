@@ -200,10 +200,14 @@ class FNO2DModule(HipBackbone):
         return self
 
     def verify(self):
-        """Deferred verification (`check="deferred"`): synchronises the current stream and raises DlwpError (status -5,
-        DLWP_ERR_TIMEOUT) if a fused launch of the current plan timed out since the last call of this method -- the
-        pattern for throughput evaluation: many asynchronous rollouts, one verification.  With the default
-        `check="per_call"` every call verifies (and repairs) itself and this is a no-op that always passes."""
+        """Deferred verification (`check="deferred"`): synchronises the current stream and raises DlwpError if a fused
+        launch of the current plan timed out (status -5, DLWP_ERR_TIMEOUT) or an f16x3 range produced a non-finite output
+        (status -6, DLWP_ERR_RANGE) since the last call of this method -- the pattern for throughput evaluation: many
+        asynchronous rollouts, one verification.  In deferred mode NOTHING is repaired: the trajectories of a failed range
+        are poisoned with NaN and this call is MANDATORY before they are used (`_get_plan` calls it by itself before a
+        plan rebuild would drop the counters).  The same holds for launches recorded into a HIP graph: the per-call check
+        cannot synchronise a capturing stream, so replays of a captured rollout are verified here, whatever `check` says.
+        With the default `check="per_call"` outside graphs every call verifies (and repairs) itself and this passes."""
         if self._plan is not None:
             with torch.cuda.device(next(self.parameters()).device):
                 _lib.check(_lib.load().dlwp_fno2d_status(self._plan, _lib.stream_ptr()), "dlwp_fno2d_status")

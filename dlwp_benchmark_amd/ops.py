@@ -2,6 +2,7 @@
 Every wrapper takes CUDA tensors, passes raw pointers + the current HIP stream, and raises
 `DlwpError` on a non-zero status.  No wrapper has a CPU path."""
 import ctypes
+import weakref
 import functools
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -103,6 +104,22 @@ def window_attention_io_supported(spec: WindowSpec, batch: int) -> bool:
     return int(_lib.load().dlwp_window_attn_workspace_bytes(ctypes.byref(d), int(batch), 1)) > 0
 
 
+_BIAS16 = {}
+
+
+def _bias_bf16(bias: torch.Tensor) -> torch.Tensor:
+    """bfloat16 image of a qkv bias (read by the earth-window kernel for zero-padded tokens), converted once per parameter
+    state instead of once per call: keyed like the packed weights (pointer, version, pack epoch of invalidate_packed())."""
+    key = (bias.data_ptr(), bias._version, str(bias.device), pack_epoch())
+    hit = _BIAS16.get(id(bias))
+    if hit is None or hit[0] != key or hit[2]() is not bias:      # (the weak reference: ids are reused after a free)
+        if len(_BIAS16) > 256:
+            _BIAS16.clear()
+        hit = (key, bias.detach().to(torch.bfloat16).contiguous(), weakref.ref(bias))
+        _BIAS16[id(bias)] = hit
+    return hit[1]
+
+
 def _window_attention_bf16_io(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], table: torch.Tensor, spec: WindowSpec):
     if not qkv.is_cuda:
         raise _lib.DlwpError("qkv must be a tensor on an MI355X device")
@@ -112,7 +129,7 @@ def _window_attention_bf16_io(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor
     c = spec.heads * spec.head_dim
     if c3 != 3 * c or l != spec.grid[0] * spec.grid[1] * spec.grid[2]:
         raise _lib.DlwpError(f"qkv shape {tuple(qkv.shape)} does not match grid {tuple(spec.grid)} x 3*{c}")
-    bias16 = qkv_bias.detach().to(torch.bfloat16).contiguous() if qkv_bias is not None else None
+    bias16 = _bias_bf16(qkv_bias) if qkv_bias is not None else None
     out = torch.empty(b, l, c, device=qkv.device, dtype=torch.bfloat16)
     lib = _lib.load()
     d = spec.to_c()
@@ -122,7 +139,7 @@ def _window_attention_bf16_io(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor
         ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=qkv.device)
         rc = lib.dlwp_window_attn_bf16_io(ctypes.byref(d), qkv.data_ptr(), bias16.data_ptr() if bias16 is not None else None,
                                           table.data_ptr(), out.data_ptr(), b, ws.data_ptr(), nbytes, _lib.stream_ptr())
-    if rc == -4:     # DLWP_ERR_UNSUPPORTED: a descriptor only the generic kernel takes -- the same arithmetic on fp32 tensors
+    if rc == -2:     # DLWP_ERR_UNSUPPORTED: a descriptor only the generic kernel takes -- the same arithmetic on fp32 tensors
         return window_attention(qkv.float(), qkv_bias, table, spec, precision="bf16").to(torch.bfloat16)
     _lib.check(rc, "dlwp_window_attn_bf16_io")
     return out

@@ -256,7 +256,7 @@ class _WindowAttentionFn(torch.autograd.Function):
                 return (gq if ctx.needs_input_grad[0] else None, gb if ctx.needs_input_grad[1] else None,
                         gt if ctx.needs_input_grad[2] else None, None, None)
             except _lib.DlwpError as e:
-                if "status -4" not in str(e):        # DLWP_ERR_UNSUPPORTED only
+                if "status -2:" not in str(e):       # DLWP_ERR_UNSUPPORTED only
                     raise
         with torch.enable_grad():
             q_ = qkv.detach().requires_grad_(ctx.needs_input_grad[0])

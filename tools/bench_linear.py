@@ -16,7 +16,7 @@ SHAPES = [   # (label, rows, in, out, act, resid)
     ("C3 s1 fc2+res", 32 * 512, 768, 192, 0, True),
     ("C5 l1 qkv", 8 * 32768, 192, 576, 0, False), ("C5 l1 proj+res", 8 * 32768, 192, 192, 0, True),
     ("C5 l1 fc1+gelu", 8 * 32768, 192, 768, 1, False), ("C5 l1 fc2+res", 8 * 32768, 768, 192, 0, True),
-    ("C5 l2 qkv", 8 * 8192, 384, 1152, 0, False), ("C5 l2 fc1+gelu", 8 * 8192, 384, 1536, 1, False),
+    ("C5 l2 qkv", 8 * 8192, 384, 1152, 0, False), ("C5 l2 proj+res", 8 * 8192, 384, 384, 0, True), ("C5 l2 fc1+gelu", 8 * 8192, 384, 1536, 1, False),
     ("C5 l2 fc2+res", 8 * 8192, 1536, 384, 0, True),
 ]
 
@@ -54,9 +54,8 @@ def main():
         out = torch.empty(rows, n, device=dev)
         xin, oo = x, out
         if args.io and args.precision == "bf16":
-            if "proj" not in label:
-                xin = x.to(torch.bfloat16)                      # LayerNorm output / GELU hidden handed over as bf16
-            if "fc1" in label:
+            xin = x.to(torch.bfloat16)                          # LayerNorm output / attention output / GELU hidden handed over as bf16
+            if "fc1" in label or "qkv" in label:
                 oo = torch.empty(rows, n, device=dev, dtype=torch.bfloat16)
         with torch.no_grad():
             def hip():

@@ -8,7 +8,7 @@ timeout -k 10 200 python bench.py --cpu-batch 1 --no-other-configs --no-second-f
 python - <<PY
 import json
 d=json.load(open("$out/bench.json"))
-print("value %.4g ms/rollout %.4f kernel_ms %.4f frac %.4f rel_l2 %.3g" % (d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"], d["rel_l2_per_step_max"]))
+print("value %.4g ms/rollout %.4f kernel_ms %.4f frac %.4f rel_l2 %.3g" % (d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"], d.get("rel_l2_max", d.get("rel_l2_per_step_max", float("nan")))))
 PY
 if [ "$2" != "notest" ]; then
 timeout -k 10 500 python -m pytest tests/test_fno_gpu.py tests/test_gelu_poly.py -m gpu -x -q > $out/pytest.log 2>&1 || { tail -30 $out/pytest.log; exit 1; }
