@@ -248,7 +248,10 @@ int32_t dlwp_window_attn_bf16(const dlwp_wattn_desc* desc, const float* qkv_dev,
 /* dlwp_window_attn_bf16 with bfloat16 TENSORS: qkv_dev [B, L, 3 C], qkv_bias_dev [3 C] and out_dev [B, L, C] are bf16 -- the
  * hand-over of a block in the bf16 form (the qkv Linear writes bf16, proj reads bf16: dlwp_linear_bf16_io).  Same arithmetic as
  * dlwp_window_attn_bf16 on bf16-rounded inputs.  Covered: the descriptors of the two fast paths (workspace as for
- * dlwp_window_attn_bf16); anything else returns DLWP_ERR_UNSUPPORTED (convert and call dlwp_window_attn_bf16). */
+ * dlwp_window_attn_bf16); anything else returns DLWP_ERR_UNSUPPORTED (convert and call dlwp_window_attn_bf16).
+ * 2-D (Swin) descriptors run WITHOUT the prep kernel: the attention kernel gathers Q, K, V from qkv_dev itself (window order and
+ * roll through an LDS token map), so the images part of the workspace stays unused; shifted blocks launch one small key-norm
+ * kernel in front.  dlwp_window_attn_fallbacks is maintained for shifted blocks only on this entry point. */
 int32_t dlwp_window_attn_bf16_io(const dlwp_wattn_desc* desc, const void* qkv_dev, const void* qkv_bias_dev,
                                  const float* table_dev, void* out_dev, int32_t batch, void* workspace_dev,
                                  size_t workspace_bytes, void* stream);

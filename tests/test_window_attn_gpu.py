@@ -178,3 +178,64 @@ def test_bf16_tensor_handover_is_bit_identical(kind):
     got = ops.window_attention(q16, bias, table, spec, precision="bf16")
     assert got.dtype == torch.bfloat16
     assert torch.equal(got, want.to(torch.bfloat16))
+
+
+def _sub_window_spec(h, w, wh, ww, heads, d, shifted):
+    """Swin block with windows smaller than the map (nwin > 1), shift = half a window (swin_transformer.py:217-251)."""
+    from dlwp_benchmark_amd import ops
+
+    sh, sw = (wh // 2, ww // 2) if shifted else (0, 0)
+    return ops.WindowSpec(grid=(1, h, w), padded=(1, h, w), pad_lead=(0, 0, 0), window=(1, wh, ww), shift_fwd=(0, sh, sw),
+                          shift_back=(0, sh, sw), use_mask=shifted, mask_b1=(ops.BIG, h - wh, w - ww),
+                          mask_b2=(ops.BIG, h - wh // 2, w - ww // 2), bias_mode=0, heads=heads, head_dim=d,
+                          scale=d ** -0.5), (2 * wh - 1) * (2 * ww - 1)
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+@pytest.mark.parametrize("h,w,wh,ww,heads,d", [(32, 64, 32, 64, 4, 24),     # C3 stage 0: one window, 64 queries per wave
+                                               (16, 32, 16, 32, 8, 48),     # C3 stage 1 head_dim
+                                               (16, 64, 8, 32, 2, 8),       # 4 windows, 256 keys each
+                                               (32, 64, 8, 32, 2, 16),      # 8 windows
+                                               (24, 96, 12, 48, 2, 24),     # window width 48: 256 % 48 != 0 (token-map carry)
+                                               (16, 160, 8, 80, 3, 8)])     # window width 80
+def test_direct_gather_form_is_bit_identical_to_the_image_form(h, w, wh, ww, heads, d, shifted):
+    """dlwp_window_attn_bf16_io on 2-D descriptors gathers Q / K / V from the bfloat16 qkv tensor inside the attention kernel
+    (round 3: no prep kernel, no operand images); dlwp_window_attn_bf16 on the same bf16-representable values still runs prep
+    kernel + images.  Same arithmetic in the same order: the outputs must agree to the last bit, for every instantiated head
+    dimension, for one and for several windows per map, power-of-two and other window widths, with and without the shift."""
+    from dlwp_benchmark_amd import ops
+
+    spec, rows = _sub_window_spec(h, w, wh, ww, heads, d, shifted)
+    if shifted and (ww // 2) % 16:
+        pytest.skip("longitude region boundary inside a 16-key block: generic kernel, no bfloat16-tensor form")
+    qkv, bias, table = _inputs(3, h, w, heads, d, rows, seed=h + ww + d, qk_gain=1.5)
+    assert ops.window_attention_io_supported(spec, 3)
+    q16 = qkv.to(torch.bfloat16)
+    want = ops.window_attention(q16.float(), bias, table, spec, precision="bf16")
+    got = ops.window_attention(q16, bias, table, spec, precision="bf16")
+    assert got.dtype == torch.bfloat16 and torch.isfinite(got.float()).all()
+    assert torch.equal(got, want.to(torch.bfloat16))
+    ref = ops.window_attention(q16.float(), bias, table, spec, precision="fp32_mfma")
+    assert rel_l2(got.float(), ref) <= 5e-2     # sanity only (bf16 operands AND a bf16 output; head_dim 8 with 1.5 x logits: 3e-2)
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_direct_gather_form_exponent_slack_fallback(shifted):
+    """The exact-maximum fallback of the direct form (scores that leave the 2^+-100 slack): still bit-identical to the image form."""
+    from dlwp_benchmark_amd import ops
+
+    spec, rows = _spec(16, 32, 2, 8, shifted)
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(1, 512, 3, 2, 8, generator=g)
+    ramp = torch.linspace(0.0, 60.0, 512).view(1, 512, 1, 1)
+    qkv[:, :, 1] = qkv[:, :, 1] * 0.1 + ramp          # keys grow along the window order: later tiles dwarf the first one
+    qkv[:, :, 0] = qkv[:, :, 0].abs() * 8.0 + 8.0
+    qkv = qkv.reshape(1, 512, 48).cuda()
+    bias = torch.zeros(48).cuda()
+    table = (torch.randn(rows, 2, generator=g) * 0.5).cuda()
+    q16 = qkv.to(torch.bfloat16)
+    want, fb = ops.window_attention(q16.float(), bias, table, spec, precision="bf16", count_fallbacks=True)
+    assert fb > 0, "the inputs were meant to leave the exponent slack"
+    got = ops.window_attention(q16, bias, table, spec, precision="bf16")
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want.to(torch.bfloat16))
