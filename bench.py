@@ -592,12 +592,24 @@ def make_runner(model, world, rank, args, prog, H, W, scorer=None):
     acc = {"sums": torch.zeros(4, K, prog.shape[2], dtype=torch.float64, device=prog.device) if args.collect == "metrics" else None,
            "samples": 0, "scores": None, "out": None}
 
-    def step(constants=None, prescribed=None):
-        out = runner(constants=constants, prescribed=prescribed, prognostic=prog)
+    def device_step(constants, prescribed, prognostic):
+        out = runner(constants=constants, prescribed=prescribed, prognostic=prognostic)
         if args.collect == "metrics":
             # this rank's squared-error sums of the rollout, ADDED to the evaluation's running sums on the device (the
             # reference accumulates over all batches before taking the root, evaluate.py:786-821): no collective per step
             acc["sums"].add_(scorer.sums(out if out.shape[0] == B else out[rank * B:(rank + 1) * B], target))
+        return out
+
+    # --graph-step: rollout + metric sums as ONE recorded HIP graph per rank (no collective inside a step in "metrics" / "none" mode)
+    graphed = None
+    if getattr(args, "graph_step", False) and prog.is_cuda and (world == 1 or args.collect != "gather"):
+        from dlwp_benchmark_amd.sharding import CapturedStep
+
+        graphed = CapturedStep(device_step, model=model)
+
+    def step(constants=None, prescribed=None):
+        out = (graphed or device_step)(constants, prescribed, prog)
+        if args.collect == "metrics":
             acc["samples"] += B
         acc["out"] = out
         return out
@@ -646,7 +658,8 @@ def run_c2(args, world, rank, device, dist, backend):
                         "1 step = 1 rollout of the batch",
             "batch_per_gpu": B, "global_batch": B * world, "grid": [H, W], "rollout_steps": K_roll,
             "parallelism": parallelism_text(world, args.collect), "collect": args.collect, "precision_form": form,
-            "launch": "eager; fused-kernel check deferred, verified once per evaluation inside the timed region",
+            "launch": ("one recorded HIP graph per step (rollout + metric sums; sharding.CapturedStep)" if getattr(args, "graph_step", False)
+                       else "eager") + "; fused-kernel check deferred, verified once per evaluation inside the timed region",
             "weights": "filler sha256:" + sha[:12],
         },
         "fused_timeouts": int(model.fused_timeouts()), "range_reruns": int(model.range_reruns()),
@@ -848,6 +861,9 @@ def main():
     ap.add_argument("--only-configs", nargs="*", help="subset of the other-config tags (C1 C3 C4 C5)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "profiles", "bench_detail_last.json"),
                     help="where the verbose result (per-kernel tables, full other-config entries) is written")
+    ap.add_argument("--graph-step", dest="graph_step", action="store_true", default=True,
+                    help="record a step (rollout + metric sums) into one HIP graph and replay it (default)")
+    ap.add_argument("--no-graph-step", dest="graph_step", action="store_false", help="enqueue every launch of a step from the host")
     ap.add_argument("--gather-chunks", type=int, default=4)
     ap.add_argument("--collect", choices=["metrics", "gather", "none"], default="metrics",
                     help="what leaves a rank per rollout: per-lead-time RMSE sums reduced on the device and all-reduced "

@@ -2782,6 +2782,25 @@ int fused_resident_per_cu(int G) {
   // size a grid beyond that even if a later compiler build would admit two
   return n >= 1 ? 1 : 0;
 }
+// xpart copy 0 | xpart copy 1 | obuf copy 0 | obuf copy 1, each as large as the B samples and the G = H / rows workgroups per sample
+// in use need; 11 + 1.4 MB at the headline shape instead of the 22 + 1.4 MB the workspace reserves (fill time per rollout)
+struct ExchangeLayout {
+  float* xpart;
+  float* obuf;
+  long long xpart_par, obuf_par;
+  size_t floats;
+};
+ExchangeLayout exchange_layout(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B) {
+  const int rows = trunk_rows(p), G = rows ? p->H / rows : (p->H + 3) / 4;
+  const size_t nm = (size_t)p->sc.M1 * p->sc.M2 * 64;                    // floats per (sample, member)
+  ExchangeLayout x;
+  x.xpart = ws.xpart;
+  x.xpart_par = (long long)((size_t)B * G * nm);
+  x.obuf = ws.xpart + 2 * (size_t)B * G * nm;
+  x.obuf_par = (long long)((size_t)B * nm);
+  x.floats = 2 * (size_t)B * G * nm + 2 * (size_t)B * nm;               // <= 2 xpart_half + 2 obuf_half (G <= H / 4)
+  return x;
+}
 int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, TrunkState& st, hipStream_t s,
                     bool force_unfused = false) {
   st.on = trunk_eligible(p) && !force_unfused;
@@ -2790,9 +2809,11 @@ int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, Tru
   if (st.on) {
     // group counters, XCC-id table and the fail word behind them
     DLWP_HIP_CHECK(hipMemsetAsync(ws.ctr, 0, 2 * align_up((size_t)B * kCtrStrideBytes, 256) + kFailBytes, s));
-    if (p->k.ll) {   // arm both copies of both exchange buffers with the sentinel
-      DLWP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.xpart), (int)kSentinel, 2 * ws.xpart_half, s));
-      DLWP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.obuf), (int)kSentinel, 2 * ws.obuf_half, s));
+    if (p->k.ll) {
+      // arm both copies of both exchange buffers with the sentinel in ONE fill: the four copies are laid out back to back for the
+      // group size in use (exchange_layout(); the workspace is cut for the largest, H / 4 workgroups per sample)
+      const ExchangeLayout x = exchange_layout(p, ws, B);
+      DLWP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(x.xpart), (int)kSentinel, x.floats, s));
     }
   }
   return DLWP_OK;
@@ -2861,11 +2882,12 @@ int32_t launch_trunk(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, co
       tp.wsb[l] = p->wsbp[ll].as<u32x4>(); tp.bias[l] = p->sbias[ll].as<float>(); tp.wt[l] = p->wt[ll].as<float2>();
     }
     tp.S = (B - s0 < per_launch) ? B - s0 : per_launch;
-    tp.xpart = ws.xpart + (size_t)s0 * G * nm;
-    tp.obuf = ws.obuf + (size_t)s0 * nm;
+    const ExchangeLayout xl = exchange_layout(p, ws, B);
+    tp.xpart = xl.xpart + (size_t)s0 * G * nm;
+    tp.obuf = xl.obuf + (size_t)s0 * nm;
     tp.ctr = ws.ctr + (size_t)s0 * (kCtrStrideBytes / 4);
     tp.epoch = st.epoch; tp.fwd_scale = p->sc.fwd_scale;
-    tp.xpart_par = (long long)ws.xpart_half; tp.obuf_par = (long long)ws.obuf_half; tp.layer0 = st.layers;
+    tp.xpart_par = xl.xpart_par; tp.obuf_par = xl.obuf_par; tp.layer0 = st.layers;
     tp.xcc_tab = ws.ctr + align_up((size_t)B * kCtrStrideBytes, 256) / 4 + (size_t)s0 * 32;
     tp.H = p->H; tp.L = p->L; tp.M1 = p->sc.M1; tp.M2 = p->sc.M2; tp.G = G; tp.sample0 = s0;
     tp.spin_limit = p->k.spin_limit; tp.try_limit = p->k.try_limit; tp.fail_word = ws.fail;

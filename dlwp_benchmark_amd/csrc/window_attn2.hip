@@ -308,9 +308,11 @@ __global__ __launch_bounds__(256, NP == 3 ? 2 : 4) void wattn2_kernel(const Geo 
       s_dst[tid] = da * G.lon + dq;
     }
   } else {
+  // (entries past the table are ZEROED, not skipped: the bound of the masked-block skip takes the maximum over the whole slice, and
+  // whatever an earlier kernel left in LDS there could flip a workgroup into its exact fallback -- correct, but not reproducible)
   for (int i = tid; i < rev_floats / 4; i += 256)
-    if (rev_lo + 4 * i < TRP)
-      reinterpret_cast<float4*>(s_rev)[i] = reinterpret_cast<const float4*>(I.rev + (long long)head * TRP + rev_lo)[i];
+    reinterpret_cast<float4*>(s_rev)[i] = rev_lo + 4 * i < TRP
+        ? reinterpret_cast<const float4*>(I.rev + (long long)head * TRP + rev_lo)[i] : float4{0.f, 0.f, 0.f, 0.f};
   }
   auto region_of = [&](int n0) {   // region id of the 16 consecutive window positions starting at n0 (one latitude row)
     const int A = ilat * G.wlat + n0 / G.wlon, O = ilon * G.wlon + n0 % G.wlon;

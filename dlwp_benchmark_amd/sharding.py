@@ -101,3 +101,52 @@ class ShardedRollout:
                 wk.wait()
                 ov[:, :, a:e].copy_(recv.view(self.world, b, e - a, cg, h, w), non_blocking=True)
             return out
+
+
+class CapturedStep:
+    """One evaluation step -- `fn(*tensors)`: a rank's rollout plus whatever device-only work follows it (metric sums) -- recorded
+    into a HIP graph at the first call with a given set of input tensors and replayed afterwards.  What it removes is the host
+    side of the step: the launches of a 20-step FNO rollout + its metric kernels are ~8 graph nodes, 90-130 us of gaps per 1.5 ms
+    rollout when enqueued one by one.
+
+    Contract (that of any captured graph): `fn` must not synchronise, must not move data to the host and must not run a collective;
+    its inputs are read from the SAME device addresses at every call (an evaluation loop stages each batch into fixed buffers:
+    dlwp_benchmark_amd.staging.DeviceStager), and from the second call on the returned tensors are the SAME objects, overwritten
+    by every replay (the first call with a set of tensors runs eagerly, the second one records).  Fused-kernel checks cannot run inside a graph: the model is verified by the caller (`model.verify()`, once per
+    evaluation) -- FNO modules are switched to `check="deferred"` here for that reason.  A call with other tensors (address, shape
+    or dtype) records a new graph."""
+
+    def __init__(self, fn, model=None):
+        self.fn = fn
+        self._key = None
+        self._graph = None
+        self._out = None
+        if model is not None and hasattr(model, "set_execution_form") and getattr(model, "check", None) == "per_call":
+            model.set_execution_form(check="deferred")
+        if model is not None and hasattr(model, "set_step_graphs"):
+            model.set_step_graphs(False)          # a graph replay cannot be recorded into another graph: the step runs eagerly ONCE
+
+    @staticmethod
+    def _key_of(tensors):
+        return tuple(None if t is None else (t.data_ptr(), tuple(t.shape), t.dtype, str(t.device)) for t in tensors)
+
+    def __call__(self, *tensors):
+        key = self._key_of(tensors)
+        if key != self._key:
+            # first call with these tensors: the step runs eagerly, ONCE (its side effects -- running sums -- count once, and plans,
+            # packed weights and workspaces come into being outside any capture); the recording happens at the next call
+            dev = next(t.device for t in tensors if t is not None)
+            if dev.type != "cuda":
+                raise RuntimeError("CapturedStep records HIP graphs: the inputs must live on an MI355X device")
+            self._key, self._graph, self._out = key, None, None
+            return self.fn(*tensors)
+        if self._graph is None:
+            dev = next(t.device for t in tensors if t is not None)
+            with torch.cuda.device(dev):
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):      # nothing executes here
+                    out = self.fn(*tensors)
+            self._graph, self._out = graph, out
+        self._graph.replay()
+        return self._out

@@ -1,0 +1,99 @@
+"""sharding.CapturedStep: an evaluation step (rollout + metric sums) recorded into a HIP graph and replayed.  The replay must
+produce what the eager step produces, follow new input VALUES at the same addresses, and re-record for other tensors."""
+import pytest
+import torch
+
+from helpers import fno_std_fn
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+NS_KW = dict(n_modes=[12, 12], constant_channels=0, prescribed_channels=0, prognostic_channels=1,
+             hidden_channels=32, lifting_channels=256, projection_channels=256, n_layers=4, context_size=1)
+
+
+def _fno():
+    from dlwp_benchmark_amd.models import FNO2DModule
+    from dlwp_benchmark_amd.weights import fill_state_dict
+
+    m = FNO2DModule(**NS_KW)
+    fill_state_dict(m, std_fn=fno_std_fn(0.85), gain=0.85)
+    return m.to(DEV).eval()
+
+
+def test_replay_equals_eager_and_follows_the_buffers():
+    from dlwp_benchmark_amd.metrics import RolloutMetrics
+    from dlwp_benchmark_amd.sharding import CapturedStep, ShardedRollout
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    model = _fno()
+    runner = ShardedRollout(model, gather=False)
+    scorer = RolloutMetrics(torch.zeros(64))
+    _, _, prog_a = navier_stokes(4, 7, 64, 64, seed=1)
+    _, _, prog_b = navier_stokes(4, 7, 64, 64, seed=2)
+    buf = prog_a.to(DEV).clone()                       # the fixed input buffer of an evaluation loop
+    target = torch.empty(4, 6, 1, 64, 64, device=DEV)
+    sums = torch.zeros(4, 6, 1, dtype=torch.float64, device=DEV)
+
+    def step(c, p, g):
+        out = runner(constants=c, prescribed=p, prognostic=g)
+        sums.add_(scorer.sums(out, target))
+        return out
+
+    want = {}
+    for name, prog in (("a", prog_a), ("b", prog_b)):
+        buf.copy_(prog.to(DEV))
+        target.copy_(buf[:, 1:])
+        sums.zero_()
+        want[name] = (step(None, None, buf).clone(), sums.clone())
+    cap = CapturedStep(step, model=model)
+    assert model.check == "deferred"
+    for name, prog in (("a", prog_a), ("b", prog_b), ("a", prog_a)):
+        buf.copy_(prog.to(DEV))
+        target.copy_(buf[:, 1:])
+        sums.zero_()
+        out = cap(None, None, buf)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want[name][0])
+        assert torch.allclose(sums, want[name][1], rtol=1e-12, atol=0)
+    model.verify()
+    first_graph = cap._graph
+    assert first_graph is not None
+    other = prog_b.to(DEV)                              # another tensor (address): eager once, then a new recording
+    target.copy_(other[:, 1:])
+    for _ in range(3):
+        sums.zero_()
+        out2 = cap(None, None, other)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, want["b"][0])
+        assert torch.allclose(sums, want["b"][1], rtol=1e-12, atol=0)
+    assert cap._graph is not None and cap._graph is not first_graph
+
+
+def test_captured_swin_rollout_matches_eager():
+    """A whole 3-step Swin rollout (constants + prescribed channels, per-step graphs switched off by CapturedStep) as one graph."""
+    import json
+
+    import dlwp_benchmark_amd.models as M
+    from dlwp_benchmark_amd.sharding import CapturedStep, ShardedRollout
+    from dlwp_benchmark_amd.weights import fill_by_spec
+    from helpers import load_golden
+    from oracle.make_golden import MODEL_CASES, model_inputs
+
+    tag = "swin_e32_32x64"
+    family, cfg, (batch, frames), gain = MODEL_CASES[tag]
+    g = load_golden(f"model_{tag}")
+    sd, _ = fill_by_spec(json.loads(str(g["param_spec"])), gain=gain)
+    c, p, x = model_inputs(tag, cfg, batch, frames)
+    model = M.SwinTransformer(**cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV).eval()
+    c, p, x = (t.to(DEV) if t is not None else None for t in (c, p, x))
+    runner = ShardedRollout(model, gather=False)
+    want = runner(constants=c, prescribed=p, prognostic=x).clone()
+    cap = CapturedStep(lambda cc, pp, gg: runner(constants=cc, prescribed=pp, prognostic=gg), model=model)
+    for i in range(3):
+        got = cap(c, p, x)
+        torch.cuda.synchronize()
+        d = (got - want).abs()
+        assert torch.equal(got, want), (i, float(d.max()), float((d > 0).float().mean()), bool(torch.isnan(got).any()), bool(torch.isnan(want).any()))
