@@ -2801,20 +2801,26 @@ ExchangeLayout exchange_layout(const dlwp_fno2d_plan* p, const FnoWorkspace& ws,
   x.floats = 2 * (size_t)B * G * nm + 2 * (size_t)B * nm;               // <= 2 xpart_half + 2 obuf_half (G <= H / 4)
   return x;
 }
+__global__ __launch_bounds__(256) void trunk_arm_kernel(u32x4* __restrict__ xch, size_t quads, unsigned* __restrict__ ctr, size_t words) {
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  const u32x4 sent = {kSentinel, kSentinel, kSentinel, kSentinel};
+  for (size_t i = i0; i < quads; i += stride) xch[i] = sent;
+  for (size_t i = i0; i < words; i += stride) ctr[i] = 0u;
+}
 int32_t trunk_begin(const dlwp_fno2d_plan* p, const FnoWorkspace& ws, int B, TrunkState& st, hipStream_t s,
                     bool force_unfused = false) {
   st.on = trunk_eligible(p) && !force_unfused;
   st.epoch = 0;
   st.layers = 0;
   if (st.on) {
-    // group counters, XCC-id table and the fail word behind them
-    DLWP_HIP_CHECK(hipMemsetAsync(ws.ctr, 0, 2 * align_up((size_t)B * kCtrStrideBytes, 256) + kFailBytes, s));
-    if (p->k.ll) {
-      // arm both copies of both exchange buffers with the sentinel in ONE fill: the four copies are laid out back to back for the
-      // group size in use (exchange_layout(); the workspace is cut for the largest, H / 4 workgroups per sample)
-      const ExchangeLayout x = exchange_layout(p, ws, B);
-      DLWP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(x.xpart), (int)kSentinel, x.floats, s));
-    }
+    // ONE launch: zero the group counters, the XCC-id table and the fail word behind them; arm both copies of both exchange buffers
+    // with the sentinel (laid out back to back for the group size in use: exchange_layout()).  A kernel of our own rather than
+    // hipMemset*Async: two fills were two more nodes in front of every rollout (~5 us each).
+    const size_t zero_words = (2 * align_up((size_t)B * kCtrStrideBytes, 256) + kFailBytes) / 4;
+    const ExchangeLayout x = exchange_layout(p, ws, B);
+    const size_t arm_quads = p->k.ll ? x.floats / 4 : 0;             // nm is a multiple of 64 floats
+    hipLaunchKernelGGL(trunk_arm_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<u32x4*>(x.xpart), arm_quads, ws.ctr, zero_words);
+    DLWP_HIP_CHECK(hipGetLastError());
   }
   return DLWP_OK;
 }
