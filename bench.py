@@ -597,7 +597,7 @@ def make_runner(model, world, rank, args, prog, H, W, scorer=None):
         if args.collect == "metrics":
             # this rank's squared-error sums of the rollout, ADDED to the evaluation's running sums on the device (the
             # reference accumulates over all batches before taking the root, evaluate.py:786-821): no collective per step
-            acc["sums"].add_(scorer.sums(out if out.shape[0] == B else out[rank * B:(rank + 1) * B], target))
+            scorer.sums(out if out.shape[0] == B else out[rank * B:(rank + 1) * B], target, into=acc["sums"])
         return out
 
     # --graph-step: rollout + metric sums as ONE recorded HIP graph per rank (no collective inside a step in "metrics" / "none" mode)

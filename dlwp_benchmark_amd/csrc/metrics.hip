@@ -65,15 +65,14 @@ __global__ __launch_bounds__(256) void weighted_sums_kernel(const float* __restr
 
 using namespace dlwp;
 
-extern "C" int32_t dlwp_weighted_error_sums_f32(const float* out, const float* target, const float* climatology,
-                                                const float* lat_weights, const float* scale, double* sums,
-                                                int32_t batch, int32_t steps, int32_t channels, int32_t height,
-                                                int32_t width, void* stream) {
+static int32_t weighted_sums(const float* out, const float* target, const float* climatology, const float* lat_weights,
+                             const float* scale, double* sums, int32_t batch, int32_t steps, int32_t channels, int32_t height,
+                             int32_t width, void* stream, bool zero_first) {
   DLWP_REQUIRE(out && target && lat_weights && sums, DLWP_ERR_INVALID_ARGUMENT, "null argument");
   DLWP_REQUIRE(batch > 0 && steps > 0 && channels > 0 && height > 0 && width > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
   DLWP_REQUIRE((long long)steps * channels <= 65535 && batch <= 65535, DLWP_ERR_UNSUPPORTED, "grid too large");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  DLWP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 4 * steps * channels, s));
+  if (zero_first) DLWP_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 4 * steps * channels, s));
   const long long HW = (long long)height * width;
   int chunks = (int)((HW + 8191) / 8192);
   if (chunks < 1) chunks = 1;
@@ -81,4 +80,20 @@ extern "C" int32_t dlwp_weighted_error_sums_f32(const float* out, const float* t
                      climatology, lat_weights, scale, sums, batch, steps, channels, height, width, chunks);
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
+}
+
+extern "C" int32_t dlwp_weighted_error_sums_f32(const float* out, const float* target, const float* climatology,
+                                                const float* lat_weights, const float* scale, double* sums,
+                                                int32_t batch, int32_t steps, int32_t channels, int32_t height,
+                                                int32_t width, void* stream) {
+  return weighted_sums(out, target, climatology, lat_weights, scale, sums, batch, steps, channels, height, width, stream, true);
+}
+
+// the same sums ADDED to what sums_dev holds: the running sums of an evaluation (evaluate.py:786-821 accumulates squared errors over
+// all batches before taking the root) without a zero-fill and an add kernel per batch
+extern "C" int32_t dlwp_weighted_error_sums_acc_f32(const float* out, const float* target, const float* climatology,
+                                                    const float* lat_weights, const float* scale, double* sums,
+                                                    int32_t batch, int32_t steps, int32_t channels, int32_t height,
+                                                    int32_t width, void* stream) {
+  return weighted_sums(out, target, climatology, lat_weights, scale, sums, batch, steps, channels, height, width, stream, false);
 }

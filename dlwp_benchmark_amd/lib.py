@@ -148,6 +148,8 @@ SIGNATURES = {
                                                ctypes.c_int64, c_void_p]),
     "dlwp_weighted_error_sums_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                c_int32, c_int32, c_int32, c_void_p]),
+    "dlwp_weighted_error_sums_acc_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                                   c_int32, c_int32, c_int32, c_void_p]),
     "dlwp_spectral_conv2d_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
 }
 

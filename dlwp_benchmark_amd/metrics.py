@@ -38,8 +38,10 @@ class RolloutMetrics:
                               self.clim.to(dev).contiguous() if self.clim is not None else None)
         return self._dev[key]
 
-    def sums(self, out: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-        """double [4, K, C] sums of this rank's samples (see dlwp_weighted_error_sums_f32)."""
+    def sums(self, out: torch.Tensor, target: torch.Tensor, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """double [4, K, C] sums of this rank's samples (see dlwp_weighted_error_sums_f32).  `into`: a [4, K, C] double tensor
+        of running sums the new ones are ADDED to (dlwp_weighted_error_sums_acc_f32: one launch per batch, no zero-fill, no add
+        kernel); it is returned."""
         _lib.require_cuda_tensor(out, "out")
         _lib.require_cuda_tensor(target, "target")
         out, target = out.contiguous(), target.contiguous()
@@ -48,13 +50,17 @@ class RolloutMetrics:
             raise _lib.DlwpError(f"target shape {tuple(target.shape)} != output shape {tuple(out.shape)}")
         dev = out.device
         latw, std, clim = self._on(dev)
-        sums = torch.empty(4, k, c, dtype=torch.float64, device=dev)
+        if into is not None:
+            _lib.require_cuda_tensor(into, "into")
+            if tuple(into.shape) != (4, k, c) or into.dtype != torch.float64 or not into.is_contiguous() or into.device != dev:
+                raise _lib.DlwpError(f"running sums must be a contiguous double [4, {k}, {c}] tensor on {dev}")
+        sums = into if into is not None else torch.empty(4, k, c, dtype=torch.float64, device=dev)
         lib = _lib.load()
+        fn = lib.dlwp_weighted_error_sums_acc_f32 if into is not None else lib.dlwp_weighted_error_sums_f32
         with torch.cuda.device(dev):
-            _lib.check(lib.dlwp_weighted_error_sums_f32(
-                out.data_ptr(), target.data_ptr(), clim.data_ptr() if clim is not None else None, latw.data_ptr(),
-                std.data_ptr() if std is not None else None, sums.data_ptr(), b, k, c, h, w, _lib.stream_ptr()),
-                "dlwp_weighted_error_sums_f32")
+            _lib.check(fn(out.data_ptr(), target.data_ptr(), clim.data_ptr() if clim is not None else None, latw.data_ptr(),
+                          std.data_ptr() if std is not None else None, sums.data_ptr(), b, k, c, h, w, _lib.stream_ptr()),
+                       "dlwp_weighted_error_sums_f32")
         return sums
 
     def __call__(self, out: torch.Tensor, target: torch.Tensor, world_size: int = 1):

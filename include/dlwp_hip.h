@@ -542,6 +542,12 @@ int32_t dlwp_weighted_error_sums_f32(const float* out_dev, const float* target_d
                                      const float* lat_weights_dev, const float* scale_dev, double* sums_dev,
                                      int32_t batch, int32_t steps, int32_t channels, int32_t height, int32_t width,
                                      void* stream);
+/* The same sums ADDED to the contents of sums_dev (the running sums of an evaluation over many batches: evaluate.py:786-821
+ * accumulates before it takes the root); the caller zeroes sums_dev once. */
+int32_t dlwp_weighted_error_sums_acc_f32(const float* out_dev, const float* target_dev, const float* climatology_dev,
+                                         const float* lat_weights_dev, const float* scale_dev, double* sums_dev,
+                                         int32_t batch, int32_t steps, int32_t channels, int32_t height, int32_t width,
+                                         void* stream);
 
 #ifdef __cplusplus
 }

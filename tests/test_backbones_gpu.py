@@ -145,6 +145,18 @@ def test_on_device_metrics_match_restated_formulas():
     got = m(out.cuda(), tar.cuda())
     np.testing.assert_allclose(got["rmse"].cpu().numpy(), want_rmse, rtol=2e-6)
     np.testing.assert_allclose(got["acc"].cpu().numpy(), want_acc, rtol=2e-6, atol=1e-7)
+    # running sums over two batches (dlwp_weighted_error_sums_acc_f32) = the sums of the whole set: the scores of an evaluation
+    # accumulated batch by batch (evaluate.py:786-821) without a zero-fill and an add per batch
+    o, t = out.cuda(), tar.cuda()
+    run = torch.zeros(4, k, c, dtype=torch.float64, device="cuda:0")
+    assert m.sums(o[:4], t[:4], into=run) is run
+    m.sums(o[4:], t[4:], into=run)
+    whole = m.sums(o, t)
+    assert torch.allclose(run, whole, rtol=1e-12, atol=0)
+    acc = m.finalize(run, float(n), h * w)
+    np.testing.assert_allclose(acc["rmse"].cpu().numpy(), want_rmse, rtol=2e-6)
+    with pytest.raises(Exception):
+        m.sums(o, t, into=torch.zeros(4, k, c, device="cuda:0"))          # float32 running sums are refused
 
 
 def test_device_stager_delivers_identical_batches():

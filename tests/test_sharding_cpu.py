@@ -107,7 +107,7 @@ class _CpuSumsMetrics:
         from dlwp_benchmark_amd.metrics import RolloutMetrics
 
         class M(RolloutMetrics):
-            def sums(self, out, target):
+            def sums(self, out, target, into=None):
                 w = self.latw.double()[None, None, None, :, None]
                 s = (self.std.double() if self.std is not None else torch.ones(out.shape[2], dtype=torch.float64))
                 s = s[None, None, :, None, None]
@@ -119,7 +119,7 @@ class _CpuSumsMetrics:
                     res[1] = (w * (o - c) * (t - c)).sum(dim=(0, 3, 4))
                     res[2] = (w * (o - c) ** 2).sum(dim=(0, 3, 4))
                     res[3] = (w * (t - c) ** 2).sum(dim=(0, 3, 4))
-                return res
+                return res if into is None else into.add_(res)
 
         return M(lats, std=std, climatology=clim)
 
