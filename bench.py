@@ -602,7 +602,9 @@ def make_runner(model, world, rank, args, prog, H, W, scorer=None):
 
     # --graph-step: rollout + metric sums as ONE recorded HIP graph per rank (no collective inside a step in "metrics" / "none" mode)
     graphed = None
-    if getattr(args, "graph_step", False) and prog.is_cuda and (world == 1 or args.collect != "gather"):
+    # (one process per GPU under torchrun keeps the plain launch sequence: a communicator's watchdog thread beside a stream capture
+    # is a combination this code has never run on real multi-GPU hardware, and the recorded step buys nothing for the long launches)
+    if getattr(args, "graph_step", False) and prog.is_cuda and world == 1:
         from dlwp_benchmark_amd.sharding import CapturedStep
 
         graphed = CapturedStep(device_step, model=model)
@@ -658,7 +660,7 @@ def run_c2(args, world, rank, device, dist, backend):
                         "1 step = 1 rollout of the batch",
             "batch_per_gpu": B, "global_batch": B * world, "grid": [H, W], "rollout_steps": K_roll,
             "parallelism": parallelism_text(world, args.collect), "collect": args.collect, "precision_form": form,
-            "launch": ("one recorded HIP graph per step (rollout + metric sums; sharding.CapturedStep)" if getattr(args, "graph_step", False)
+            "launch": ("one recorded HIP graph per step (rollout + metric sums; sharding.CapturedStep)" if (getattr(args, "graph_step", False) and world == 1)
                        else "eager") + "; fused-kernel check deferred, verified once per evaluation inside the timed region",
             "weights": "filler sha256:" + sha[:12],
         },

@@ -145,7 +145,8 @@ class CapturedStep:
             with torch.cuda.device(dev):
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):      # nothing executes here
+                # (thread-local error mode: other threads of the process -- a communicator's watchdog -- may touch the device meanwhile)
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # nothing executes here
                     out = self.fn(*tensors)
             self._graph, self._out = graph, out
         self._graph.replay()
