@@ -51,7 +51,8 @@ class RolloutMetrics:
         dev = out.device
         latw, std, clim = self._on(dev)
         if into is not None:
-            _lib.require_cuda_tensor(into, "into")
+            if not isinstance(into, torch.Tensor) or not into.is_cuda:
+                raise _lib.DlwpError("running sums must be a tensor on an MI355X device")
             if tuple(into.shape) != (4, k, c) or into.dtype != torch.float64 or not into.is_contiguous() or into.device != dev:
                 raise _lib.DlwpError(f"running sums must be a contiguous double [4, {k}, {c}] tensor on {dev}")
         sums = into if into is not None else torch.empty(4, k, c, dtype=torch.float64, device=dev)
