@@ -63,10 +63,112 @@ __global__ __launch_bounds__(256) void patch_embed_1x1_kernel(const float* __res
   }
 }
 
+// The other end of a 1x1-patch token backbone (reference fourcastnet.py:144 `head = nn.Linear(embed_dim, out_chans p1 p2, bias=False)`,
+// applied at :296-303 and rearranged "b h w (p1 p2 c_out) -> b c_out (h p1) (w p2)"): with 1x1 patches that is
+//   out[b][co][hw] = bias[co] + sum_c W[co][c] tokens[b][hw][c]
+// -- a [tokens x C] x [C x 3] product whose result torch writes token-major (rocBLAS, 93 us at C4) and then permutes into a
+// channels-first copy.  Here: a wave stages 64 consecutive token rows into its LDS slice with coalesced 16-byte loads, then lane =
+// token walks its row against the weight rows (LDS broadcast reads) and stores channels-first, 256 contiguous bytes per wave and
+// output channel.  fp32 FMAs in k order.
+template <int COUT_MAX>
+__global__ void patch_recover_1x1_kernel(const float* __restrict__ tok, const float* __restrict__ w,
+                                         const float* __restrict__ bias, float* __restrict__ out, long long B, long long HW,
+                                         int C, int cout) {
+  extern __shared__ __align__(16) float smem_pr[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const int ld = C + 4;                                     // row stride of the token tile (floats): 16-byte aligned rows
+  float* s_w = smem_pr;                                     // [COUT_MAX][C]
+  float* s_x = smem_pr + COUT_MAX * C + wv * 64 * ld;       // [64][ld] of this wave
+  for (int i = threadIdx.x; i < COUT_MAX * C; i += blockDim.x) s_w[i] = i < cout * C ? w[i] : 0.f;
+  __syncthreads();
+  const long long total = B * HW;
+  const long long wave_id = (long long)blockIdx.x * nwv + wv, nwave = (long long)gridDim.x * nwv;
+  const int c4 = C >> 2;
+  for (long long t0 = wave_id * 64; t0 < total; t0 += nwave * 64) {
+    const long long left = total - t0;
+    const int nt = left < 64 ? (int)left : 64;
+    const f32x4* src = reinterpret_cast<const f32x4*>(tok + t0 * C);
+    // eight 16-byte loads in flight per lane, then their LDS stores (a load-then-store loop pays one memory latency per 1 KB)
+    const int nq = nt * c4;
+    for (int i0 = lane; i0 < nq; i0 += 64 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        v[u] = i < nq ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        if (i < nq) {
+          const int r = i / c4, q = i - r * c4;
+          *reinterpret_cast<f32x4*>(s_x + r * ld + 4 * q) = v[u];
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nt) {
+      float acc[COUT_MAX];
+#pragma unroll
+      for (int co = 0; co < COUT_MAX; ++co) acc[co] = (bias && co < cout) ? bias[co] : 0.f;
+      const float* xr = s_x + lane * ld;
+      for (int q = 0; q < c4; ++q) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+#pragma unroll
+        for (int co = 0; co < COUT_MAX; ++co) {
+          const f32x4 wv4 = *reinterpret_cast<const f32x4*>(s_w + co * C + 4 * q);
+          acc[co] = fmaf(wv4[0], xv[0], acc[co]);
+          acc[co] = fmaf(wv4[1], xv[1], acc[co]);
+          acc[co] = fmaf(wv4[2], xv[2], acc[co]);
+          acc[co] = fmaf(wv4[3], xv[3], acc[co]);
+        }
+      }
+      const long long tk = t0 + lane, b = tk / HW, hw = tk - b * HW;
+#pragma unroll
+      for (int co = 0; co < COUT_MAX; ++co)
+        if (co < cout) out[(b * cout + co) * HW + hw] = acc[co];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next chunk overwrites the slice
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace embed
 }  // namespace dlwp
 
 using namespace dlwp;
+
+extern "C" int32_t dlwp_patch_recover_1x1_f32(const float* tokens_dev, const float* w_dev, const float* bias_dev, float* out_dev,
+                                              int32_t batch, int64_t tokens, int32_t channels, int32_t out_channels, void* stream) {
+  DLWP_REQUIRE(tokens_dev && w_dev && out_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(batch > 0 && tokens > 0 && channels > 0 && out_channels > 0, DLWP_ERR_INVALID_ARGUMENT, "bad shape");
+  DLWP_REQUIRE(channels % 4 == 0 && channels <= 256, DLWP_ERR_UNSUPPORTED, "patch recover: channels %d (a multiple of 4, <= 256)", channels);
+  DLWP_REQUIRE(out_channels <= 16, DLWP_ERR_UNSUPPORTED, "patch recover: out_channels %d > 16", out_channels);
+  DLWP_REQUIRE((reinterpret_cast<uintptr_t>(tokens_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_dev) & 15) == 0,
+               DLWP_ERR_INVALID_ARGUMENT, "pointers must be 16-byte aligned");
+  const int waves = channels <= 128 ? 4 : 2;
+  const int cmax = out_channels <= 4 ? 4 : (out_channels <= 8 ? 8 : 16);
+  const size_t lds = ((size_t)cmax * channels + (size_t)waves * 64 * (channels + 4)) * 4;
+  const long long total = (long long)batch * tokens;
+  long long blocks = (total + 64 * waves - 1) / (64 * waves);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define DLWP_PR(N)                                                                                                              \
+  do {                                                                                                                          \
+    auto kern = embed::patch_recover_1x1_kernel<N>;                                                                             \
+    if (lds > 48 * 1024)                                                                                                        \
+      DLWP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * waves), lds, s, tokens_dev, w_dev, bias_dev, out_dev,            \
+                       (long long)batch, (long long)tokens, channels, out_channels);                                            \
+  } while (0)
+  if (cmax == 4) DLWP_PR(4);
+  else if (cmax == 8) DLWP_PR(8);
+  else DLWP_PR(16);
+#undef DLWP_PR
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}
 
 extern "C" int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_dev, const float* bias_dev,
                                             const float* pos_dev, float* out_dev, int32_t batch, int32_t in_channels,

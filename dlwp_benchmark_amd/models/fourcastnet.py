@@ -163,8 +163,11 @@ class FourCastNet(HipBackbone):
         for i, blk in enumerate(self.blocks):
             nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
             x, l_cf = blk(x, l_cf, nxt)
-        x = self.head(x)
         p1, p2 = self.patch_size
+        if (p1, p2) == (1, 1) and not (self.training and torch.is_grad_enabled()) and \
+                ops.patch_recover_1x1_supported(self.embed_dim, self.out_chans):
+            return ops.patch_recover_1x1(x, self.head.weight, self.head.bias, self.h, self.w)   # head + rearrange in one pass
+        x = self.head(x)
         return x.view(b, self.h, self.w, p1, p2, self.out_chans).permute(0, 5, 1, 3, 2, 4).reshape(
             b, self.out_chans, self.h * p1, self.w * p2)
 

@@ -647,6 +647,29 @@ def patch_embed_1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     return out
 
 
+def patch_recover_1x1_supported(channels: int, out_channels: int) -> bool:
+    return channels % 4 == 0 and channels <= 256 and 0 < out_channels <= 16
+
+
+def patch_recover_1x1(tokens: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], h: int, w: int) -> torch.Tensor:
+    """tokens [B, H, W, C] (or [B, H*W, C]) token-major, weight [Cout, C] (the head Linear of a 1x1-patch backbone) ->
+    [B, Cout, H, W] = head(tokens) rearranged "b h w c -> b c h w"   (fourcastnet.py:144, :296-303)."""
+    _lib.require_cuda_tensor(tokens, "tokens")
+    tokens = tokens.contiguous()
+    b, c = tokens.shape[0], tokens.shape[-1]
+    cout = weight.shape[0]
+    if tokens.numel() != b * h * w * c:
+        raise _lib.DlwpError(f"patch recover: tokens {tuple(tokens.shape)} do not hold {h} x {w} tokens per sample")
+    out = torch.empty(b, cout, h, w, device=tokens.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(tokens.device):
+        _lib.check(lib.dlwp_patch_recover_1x1_f32(tokens.data_ptr(), weight.detach().contiguous().data_ptr(),
+                                                  bias.detach().contiguous().data_ptr() if bias is not None else None,
+                                                  out.data_ptr(), b, h * w, c, cout, _lib.stream_ptr()),
+                   "dlwp_patch_recover_1x1_f32")
+    return out
+
+
 def token_mlp_supported(channels: int, hidden: int) -> bool:
     """True when dlwp_token_mlp_f32 handles this (channels, hidden) pair."""
     return int(_lib.load().dlwp_token_mlp_packed_bytes(int(channels), int(hidden))) > 0

@@ -474,6 +474,14 @@ int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_dev, const f
                                  float* out_dev, int32_t batch, int32_t in_channels, int64_t tokens, int32_t channels,
                                  void* stream);
 
+/* Head of a 1x1-patch token backbone (reference fourcastnet.py:144 `head = nn.Linear(embed_dim, out_chans * p1 * p2, bias=False)`, applied
+ * at :296-303 with the rearrange "b h w (p1 p2 c_out) -> b c_out (h p1) (w p2)"; p1 = p2 = 1):
+ *   out[b][co][t] = bias[co] + sum_c w[co][c] tokens[b][t][c]
+ * tokens_dev [batch][tokens][channels] token-major, w_dev [out_channels][channels], bias_dev [out_channels] or NULL, out_dev
+ * [batch][out_channels][tokens] channels-first (NCHW with tokens = H*W).  channels a multiple of 4, <= 256; out_channels <= 16. */
+int32_t dlwp_patch_recover_1x1_f32(const float* tokens_dev, const float* w_dev, const float* bias_dev, float* out_dev,
+                                   int32_t batch, int64_t tokens, int32_t channels, int32_t out_channels, void* stream);
+
 /* Token MLP of the AFNO block (reference fourcastnet.py:41-57 `Mlp` = fc1 -> GELU -> fc2, called at :191-192 as
  * `x = mlp(norm2(x)) + residual`):  out[t] = resid[t] + b2 + W2 gelu(W1 n[t] + b1), all token-major [tokens][channels].
  * One launch; the [tokens][hidden] activation never reaches memory (both GEMMs on the bf16 matrix pipe as six-term

@@ -163,3 +163,24 @@ def test_token_mlp_rejects_unsupported_width():
     assert not ops.token_mlp_supported(64, 96)
     with pytest.raises(_lib.DlwpError):
         ops.TokenMlpWeights().get(torch.zeros(384, 96, device="cuda:0"), torch.zeros(96, 384, device="cuda:0"))
+
+
+@pytest.mark.parametrize("b,h,w,c,cout,bias", [(2, 32, 64, 64, 3, False), (3, 8, 24, 64, 3, True), (1, 16, 20, 128, 5, True),
+                                               (2, 8, 8, 256, 13, False), (1, 4, 6, 16, 1, False)])
+def test_patch_recover_1x1_matches_linear_and_rearrange(b, h, w, c, cout, bias):
+    """dlwp_patch_recover_1x1_f32 = the head Linear of a 1x1-patch backbone + "b h w c -> b c h w" (fourcastnet.py:144, :296-303)
+    in one pass, against float64 (token counts that are not multiples of 64, a wave tile that straddles two samples)."""
+    import torch.nn.functional as F
+
+    from dlwp_benchmark_amd import ops
+
+    g = torch.Generator().manual_seed(b * 100 + c + cout)
+    x = torch.randn(b, h, w, c, generator=g).cuda()
+    wt = (torch.randn(cout, c, generator=g) / c ** 0.5).cuda()
+    bs = torch.randn(cout, generator=g).cuda() if bias else None
+    assert ops.patch_recover_1x1_supported(c, cout)
+    got = ops.patch_recover_1x1(x, wt, bs, h, w)
+    want = F.linear(x.double(), wt.double(), bs.double() if bias else None).permute(0, 3, 1, 2)
+    assert got.shape == (b, cout, h, w) and got.is_contiguous()
+    err = float((got.double() - want).norm() / want.norm())
+    assert err <= 3e-7, err
