@@ -6,8 +6,8 @@ norm2,mlp.{fc1,fc2}}`, the unused `norm`, `head`) and forward signature.
 Per block: LayerNorm 1 -> channels-first (HIP), hipFFT R2C, the AFNO2D frequency-domain work (:87-121: four
 full-size zero buffers, slice-assigns, eight einsums, ReLU, softshrink) as ONE in-place HIP kernel that also carries
 the "ortho" factors, hipFFT C2R, one merge kernel (+ bias path, first skip, back to tokens) and one token-MLP kernel
-(LayerNorm 2 -> fc1 -> GELU -> fc2 -> second skip).  Patch + position embedding is one kernel for 1x1 patches; the
-head is a torch GEMM.
+(LayerNorm 2 -> fc1 -> GELU -> fc2 -> second skip).  Patch + position embedding is one kernel for 1x1 patches, and so is
+the head + rearrange at the other end (dlwp_patch_recover_1x1_f32; other patch sizes: torch GEMM + view).
 The rollout is device resident and does NOT reproduce the reference's crash on the second step
 (`.to()` on a list, :336-340) nor its per-step `.cpu()` (:359).
 """
