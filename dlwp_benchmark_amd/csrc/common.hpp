@@ -219,10 +219,12 @@ __device__ __forceinline__ void gelu_erf8(f32x4& u, f32x4& v) {
       "v_pk_fma_f32 %2, %2, %14, %21 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
       "v_pk_fma_f32 %3, %3, %15, %21 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
       "v_max_f32_e32 %6, 0, %18\n\t"
+#ifndef DLWP_KO_GELU_DEG4   /* TIMING EXPERIMENT ONLY (tools/ab_build2.sh): one Horner step less = what a degree-4 fit would cost */
       "v_pk_fma_f32 %0, %0, %12, %22 op_sel_hi:[1,1,0]\n\t"
       "v_pk_fma_f32 %1, %1, %13, %22 op_sel_hi:[1,1,0]\n\t"
       "v_pk_fma_f32 %2, %2, %14, %22 op_sel_hi:[1,1,0]\n\t"
       "v_pk_fma_f32 %3, %3, %15, %22 op_sel_hi:[1,1,0]\n\t"
+#endif
       "v_max_f32_e32 %7, 0, %19\n\t"
       "v_pk_fma_f32 %0, %0, %12, %22 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
       "v_pk_fma_f32 %1, %1, %13, %22 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
