@@ -113,14 +113,15 @@ class CapturedStep:
     its inputs are read from the SAME device addresses at every call (an evaluation loop stages each batch into fixed buffers:
     dlwp_benchmark_amd.staging.DeviceStager), and from the second call on the returned tensors are the SAME objects, overwritten
     by every replay (the first call with a set of tensors runs eagerly, the second one records).  Fused-kernel checks cannot run inside a graph: the model is verified by the caller (`model.verify()`, once per
-    evaluation) -- FNO modules are switched to `check="deferred"` here for that reason.  A call with other tensors (address, shape
-    or dtype) records a new graph."""
+    evaluation) -- FNO modules are switched to `check="deferred"` here for that reason.  Every distinct set of input tensors (address,
+    shape, dtype) gets its own recording, up to `max_graphs` (a double-buffered `DeviceStager(fixed_buffers=True)` alternates between
+    two sets; with `split_size`, two per sub-batch)."""
 
-    def __init__(self, fn, model=None):
+    def __init__(self, fn, model=None, max_graphs: int = 8):
         self.fn = fn
-        self._key = None
-        self._graph = None
-        self._out = None
+        self.max_graphs = int(max_graphs)
+        self._seen = {}          # key -> None (ran eagerly once) | (graph, outputs); insertion order = age
+        self.replays = 0
         if model is not None and hasattr(model, "set_execution_form") and getattr(model, "check", None) == "per_call":
             model.set_execution_form(check="deferred")
         if model is not None and hasattr(model, "set_step_graphs"):
@@ -130,17 +131,26 @@ class CapturedStep:
     def _key_of(tensors):
         return tuple(None if t is None else (t.data_ptr(), tuple(t.shape), t.dtype, str(t.device)) for t in tensors)
 
+    @property
+    def _graph(self):            # the most recently used recording (tests)
+        live = [v for v in self._seen.values() if v is not None]
+        return live[-1][0] if live else None
+
     def __call__(self, *tensors):
         key = self._key_of(tensors)
-        if key != self._key:
+        if key not in self._seen:
             # first call with these tensors: the step runs eagerly, ONCE (its side effects -- running sums -- count once, and plans,
-            # packed weights and workspaces come into being outside any capture); the recording happens at the next call
+            # packed weights and workspaces come into being outside any capture); the recording happens at the next call.
+            # One recording per set of input addresses (a double-buffered stager alternates between two), oldest dropped first.
             dev = next(t.device for t in tensors if t is not None)
             if dev.type != "cuda":
                 raise RuntimeError("CapturedStep records HIP graphs: the inputs must live on an MI355X device")
-            self._key, self._graph, self._out = key, None, None
+            while len(self._seen) >= self.max_graphs:
+                self._seen.pop(next(iter(self._seen)))
+            self._seen[key] = None
             return self.fn(*tensors)
-        if self._graph is None:
+        entry = self._seen.pop(key)               # re-inserted below: most recently used last
+        if entry is None:
             dev = next(t.device for t in tensors if t is not None)
             with torch.cuda.device(dev):
                 torch.cuda.synchronize()
@@ -148,6 +158,8 @@ class CapturedStep:
                 # (thread-local error mode: other threads of the process -- a communicator's watchdog -- may touch the device meanwhile)
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # nothing executes here
                     out = self.fn(*tensors)
-            self._graph, self._out = graph, out
-        self._graph.replay()
-        return self._out
+            entry = (graph, out)
+        self._seen[key] = entry
+        entry[0].replay()
+        self.replays += 1
+        return entry[1]

@@ -119,3 +119,46 @@ def test_captured_swin_rollout_matches_eager():
         torch.cuda.synchronize()
         d = (got - want).abs()
         assert torch.equal(got, want), (i, float(d.max()), float((d > 0).float().mean()), bool(torch.isnan(got).any()), bool(torch.isnan(want).any()))
+
+
+def test_fixed_buffer_stager_feeds_recorded_steps():
+    """An evaluation loop as INTEGRATION.md shows it: DeviceStager(fixed_buffers=True) alternates between two sets of device tensors,
+    CapturedStep keeps one recording per set; from the third batch on every step is a replay, every batch's trajectory equals the
+    eager one, and the running metric sums equal the sums over all batches."""
+    from dlwp_benchmark_amd.metrics import RolloutMetrics
+    from dlwp_benchmark_amd.sharding import CapturedStep, ShardedRollout
+    from dlwp_benchmark_amd.staging import DeviceStager
+    from dlwp_benchmark_amd.synthetic import navier_stokes
+
+    model = _fno()
+    runner = ShardedRollout(model, gather=False)
+    scorer = RolloutMetrics(torch.zeros(64))
+    batches = []
+    for seed in range(7):
+        _, _, prog = navier_stokes(4, 6, 64, 64, seed=100 + seed)
+        nan = torch.full((1,), float("nan"))                      # the dataset's marker of an absent input (datasets.py:317)
+        batches.append((nan, nan, prog, prog[:, 1:].contiguous()))
+    want_out, want_sums = [], torch.zeros(4, 5, 1, dtype=torch.float64, device=DEV)
+    for c, p, x, t in batches:
+        o = runner(constants=None, prescribed=None, prognostic=x.to(DEV))
+        want_out.append(o.clone())
+        want_sums += scorer.sums(o, t.to(DEV))
+    run = torch.zeros(4, 5, 1, dtype=torch.float64, device=DEV)
+
+    def step(c, p, x, t):
+        out = runner(constants=c, prescribed=p, prognostic=x)
+        scorer.sums(out, t, into=run)
+        return out
+
+    cap = CapturedStep(step, model=model)
+    seen = set()
+    for i, (c, p, x, t) in enumerate(DeviceStager(batches, DEV, fixed_buffers=True)):
+        assert c is None and p is None
+        seen.add(x.data_ptr())
+        out = cap(c, p, x, t)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want_out[i]), i
+    model.verify()
+    assert len(seen) == 2, "two alternating buffer sets"
+    assert cap.replays == 5                                       # batches 0, 1 eager (one per set); 2, 3 record + replay; 4, 5, 6 replay
+    assert torch.allclose(run, want_sums, rtol=1e-12, atol=0)
