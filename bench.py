@@ -602,6 +602,7 @@ def make_runner(model, world, rank, args, prog, H, W, scorer=None):
 
     # --graph-step: rollout + metric sums as ONE recorded HIP graph per rank (no collective inside a step in "metrics" / "none" mode)
     graphed = None
+    state = {"graph_error": None}
     # (one process per GPU under torchrun keeps the plain launch sequence: a communicator's watchdog thread beside a stream capture
     # is a combination this code has never run on real multi-GPU hardware, and the recorded step buys nothing for the long launches)
     if getattr(args, "graph_step", False) and prog.is_cuda and world == 1:
@@ -610,7 +611,19 @@ def make_runner(model, world, rank, args, prog, H, W, scorer=None):
         graphed = CapturedStep(device_step, model=model)
 
     def step(constants=None, prescribed=None):
-        out = (graphed or device_step)(constants, prescribed, prog)
+        nonlocal graphed
+        if graphed is not None:
+            try:
+                out = graphed(constants, prescribed, prog)
+            except Exception as e:      # a failed recording must not cost the line: say so (stderr + config.launch) and go on eagerly
+                print(f"bench: graph recording failed ({type(e).__name__}: {e}); continuing with plain launches", file=sys.stderr, flush=True)
+                state["graph_error"] = f"{type(e).__name__}: {e}"[:120]
+                acc["graph_error"] = state["graph_error"]
+                graphed = None
+                torch.cuda.synchronize()
+                out = device_step(constants, prescribed, prog)
+        else:
+            out = device_step(constants, prescribed, prog)
         if args.collect == "metrics":
             acc["samples"] += B
         acc["out"] = out
@@ -660,7 +673,8 @@ def run_c2(args, world, rank, device, dist, backend):
                         "1 step = 1 rollout of the batch",
             "batch_per_gpu": B, "global_batch": B * world, "grid": [H, W], "rollout_steps": K_roll,
             "parallelism": parallelism_text(world, args.collect), "collect": args.collect, "precision_form": form,
-            "launch": ("one recorded HIP graph per step (rollout + metric sums; sharding.CapturedStep)" if (getattr(args, "graph_step", False) and world == 1)
+            "launch": (("plain launches (graph recording FAILED: " + acc["graph_error"] + ")") if acc.get("graph_error") else
+                       "one recorded HIP graph per step (rollout + metric sums; sharding.CapturedStep)" if (getattr(args, "graph_step", False) and world == 1)
                        else "eager") + "; fused-kernel check deferred, verified once per evaluation inside the timed region",
             "weights": "filler sha256:" + sha[:12],
         },
