@@ -192,3 +192,60 @@ extern "C" int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_d
   DLWP_HIP_CHECK(hipGetLastError());
   return DLWP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// `_prepare_inputs` of the rollout loop (reference swin_transformer.py:679-692 and its copies): cat([constants[:, 0], prescribed window,
+// prognostic window], dim 1) -- up to 8 channel segments, each a [B][Ci][HW] block with its own batch stride (views into the inputs and
+// into the trajectory buffer), into one contiguous [B][sum Ci][HW] tensor.  torch.cat's generic kernel takes 17.6 us for the 2 MB of a
+// Swin step (26.5 us for FourCastNet's 33 MB); this is a plain 16-byte copy.
+// ---------------------------------------------------------------------------------------------------------------
+namespace dlwp {
+namespace embed {
+struct ConcatSegs {
+  const float* ptr[8];
+  long long bstride[8];      // floats between samples of the segment
+  int c0[9];                 // first destination channel of segment i; c0[n] = total channels
+  int n;
+};
+__global__ __launch_bounds__(256) void concat_channels_kernel(const ConcatSegs S, float* __restrict__ dst, long long HW4, int B) {
+  // grid.y = destination channel, grid.z = sample, grid.x strides over the plane in float4
+  const int c = blockIdx.y, b = blockIdx.z;
+  int seg = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < S.n && c >= S.c0[i]) seg = i;
+  const f32x4* src = reinterpret_cast<const f32x4*>(S.ptr[seg] + (long long)b * S.bstride[seg]) + (long long)(c - S.c0[seg]) * HW4;
+  f32x4* out = reinterpret_cast<f32x4*>(dst) + ((long long)b * S.c0[S.n] + c) * HW4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW4; i += (long long)gridDim.x * 256) out[i] = src[i];
+}
+}  // namespace embed
+}  // namespace dlwp
+
+extern "C" int32_t dlwp_concat_channels_f32(const float* const* seg_dev_ptrs, const int32_t* seg_channels, const int64_t* seg_batch_strides,
+                                            int32_t n_segments, float* out_dev, int32_t batch, int64_t plane, void* stream) {
+  DLWP_REQUIRE(seg_dev_ptrs && seg_channels && seg_batch_strides && out_dev, DLWP_ERR_INVALID_ARGUMENT, "null argument");
+  DLWP_REQUIRE(n_segments >= 1 && n_segments <= 8, DLWP_ERR_UNSUPPORTED, "concat: %d segments (1..8)", n_segments);
+  DLWP_REQUIRE(batch > 0 && batch <= 65535 && plane > 0 && plane % 4 == 0, DLWP_ERR_UNSUPPORTED,
+               "concat: batch %d, plane %lld (a multiple of 4 floats)", batch, (long long)plane);
+  embed::ConcatSegs S = {};
+  S.n = n_segments;
+  int tot = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    DLWP_REQUIRE(seg_dev_ptrs[i] && seg_channels[i] > 0, DLWP_ERR_INVALID_ARGUMENT, "concat: segment %d", i);
+    DLWP_REQUIRE((reinterpret_cast<uintptr_t>(seg_dev_ptrs[i]) & 15) == 0 && seg_batch_strides[i] % 4 == 0, DLWP_ERR_INVALID_ARGUMENT,
+                 "concat: segment %d is not 16-byte aligned", i);
+    S.ptr[i] = seg_dev_ptrs[i];
+    S.bstride[i] = seg_batch_strides[i];
+    S.c0[i] = tot;
+    tot += seg_channels[i];
+  }
+  S.c0[n_segments] = tot;
+  DLWP_REQUIRE(tot <= 65535 && (reinterpret_cast<uintptr_t>(out_dev) & 15) == 0, DLWP_ERR_UNSUPPORTED, "concat: %d channels / unaligned output", tot);
+  const long long hw4 = plane / 4;
+  int gx = (int)((hw4 + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(embed::concat_channels_kernel, dim3(gx, tot, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, out_dev,
+                     hw4, batch);
+  DLWP_HIP_CHECK(hipGetLastError());
+  return DLWP_OK;
+}

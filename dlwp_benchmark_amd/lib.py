@@ -132,6 +132,7 @@ SIGNATURES = {
                                       ctypes.c_int64, c_int32, c_float, c_void_p]),
     "dlwp_patch_embed_1x1_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, ctypes.c_int64,
                                            c_int32, c_void_p]),
+    "dlwp_concat_channels_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, ctypes.c_int64, c_void_p]),
     "dlwp_patch_recover_1x1_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64, c_int32, c_int32, c_void_p]),
     "dlwp_token_mlp_packed_bytes": (c_size_t, [c_int32, c_int32]),
     "dlwp_token_mlp_pack_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,

@@ -647,6 +647,34 @@ def patch_embed_1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     return out
 
 
+def concat_channels(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """torch.cat(parts, dim=1) for [B, Ci, H, W] float32 tensors whose (Ci, H, W) block is contiguous (any batch stride: views into the
+    inputs and the trajectory buffer) -- `_prepare_inputs` of the rollout loop (swin_transformer.py:679-692) as one 16-byte copy kernel.
+    Parts the kernel does not take (other dtypes, inner strides, > 8 parts, plane not a multiple of 4) go through torch.cat: the same
+    copy, written by torch."""
+    parts = list(parts)
+    p0 = parts[0]
+    b, h, w = p0.shape[0], p0.shape[2], p0.shape[3]
+    plane = h * w
+    ok = 1 <= len(parts) <= 8 and plane % 4 == 0 and b <= 65535
+    for t in parts:
+        ok = ok and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.shape[0] == b and tuple(t.shape[2:]) == (h, w) \
+            and t.stride(3) == 1 and t.stride(2) == w and t.stride(1) == plane and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+    if not ok:
+        return torch.cat(parts, dim=1)
+    n = len(parts)
+    ctot = sum(int(t.shape[1]) for t in parts)
+    out = torch.empty(b, ctot, h, w, device=p0.device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in parts])
+    chans = (ctypes.c_int32 * n)(*[int(t.shape[1]) for t in parts])
+    strides = (ctypes.c_int64 * n)(*[int(t.stride(0)) for t in parts])
+    lib = _lib.load()
+    with torch.cuda.device(p0.device):
+        _lib.check(lib.dlwp_concat_channels_f32(ptrs, chans, strides, n, out.data_ptr(), b, plane, _lib.stream_ptr()),
+                   "dlwp_concat_channels_f32")
+    return out
+
+
 def patch_recover_1x1_supported(channels: int, out_channels: int) -> bool:
     return channels % 4 == 0 and channels <= 256 and 0 < out_channels <= 16
 

@@ -482,6 +482,13 @@ int32_t dlwp_patch_embed_1x1_f32(const float* x_dev, const float* w_dev, const f
 int32_t dlwp_patch_recover_1x1_f32(const float* tokens_dev, const float* w_dev, const float* bias_dev, float* out_dev,
                                    int32_t batch, int64_t tokens, int32_t channels, int32_t out_channels, void* stream);
 
+/* `_prepare_inputs` of the rollout loop (reference swin_transformer.py:679-692 and its copies in fno.py:49-62, fourcastnet.py:294-307,
+ * panguweather.py:442-455, unet.py:316-329): cat([constants[:, 0], prescribed window, prognostic window], dim = 1).  n_segments <= 8 blocks
+ * [batch][seg_channels[i]][plane] whose samples lie seg_batch_strides[i] floats apart (views into the inputs / the trajectory buffer) are
+ * copied into out_dev [batch][sum channels][plane], contiguous.  The three arrays are HOST arrays; plane a multiple of 4, 16-byte alignment. */
+int32_t dlwp_concat_channels_f32(const float* const* seg_dev_ptrs, const int32_t* seg_channels, const int64_t* seg_batch_strides,
+                                 int32_t n_segments, float* out_dev, int32_t batch, int64_t plane, void* stream);
+
 /* Token MLP of the AFNO block (reference fourcastnet.py:41-57 `Mlp` = fc1 -> GELU -> fc2, called at :191-192 as
  * `x = mlp(norm2(x)) + residual`):  out[t] = resid[t] + b2 + W2 gelu(W1 n[t] + b1), all token-major [tokens][channels].
  * One launch; the [tokens][hidden] activation never reaches memory (both GEMMs on the bf16 matrix pipe as six-term

@@ -530,3 +530,25 @@ def test_full_width_rollout_at_configured_horizon(tag, precision):
     errs = per_step_rel_l2(got, want)
     print(tag, precision, "per-step rel L2:", ["%.2e" % e for e in errs])
     assert max(errs) <= (5e-3 if precision in ("bf16", "bf16all") else TOL), errs
+
+
+def test_concat_channels_equals_torch_cat_on_rollout_views():
+    """ops.concat_channels (dlwp_concat_channels_f32) on the views `_prepare_inputs` concatenates (swin_transformer.py:679-692):
+    constants[:, 0], a window of the prescribed frames flattened (t c), input frames and frames of the trajectory buffer -- all with
+    their own batch strides; bit-equal to torch.cat, and shapes the kernel does not take still come out right (torch.cat)."""
+    from dlwp_benchmark_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    b, h, w = 5, 32, 64
+    const = torch.randn(b, 1, 4, h, w, generator=g).cuda()
+    presc = torch.randn(b, 9, 2, h, w, generator=g).cuda()
+    prog = torch.randn(b, 3, 3, h, w, generator=g).cuda()
+    traj = torch.randn(b, 6, 3, h, w, generator=g).cuda()
+    parts = [const[:, 0], presc[:, 2:4].reshape(b, 4, h, w), prog[:, 2], traj[:, 0], traj[:, 4]]
+    got = ops.concat_channels(parts)
+    assert got.is_contiguous() and torch.equal(got, torch.cat(parts, dim=1))
+    assert torch.equal(ops.concat_channels([prog[:, 1]]), prog[:, 1])
+    odd = [torch.randn(2, 3, 5, 7, generator=g).cuda(), torch.randn(2, 1, 5, 7, generator=g).cuda()]     # 35 cells per plane
+    assert torch.equal(ops.concat_channels(odd), torch.cat(odd, dim=1))
+    sliced = [prog[:, 0][:, :, :, ::2], traj[:, 1][:, :, :, ::2]]                                           # inner stride 2
+    assert torch.equal(ops.concat_channels(sliced), torch.cat(sliced, dim=1))
