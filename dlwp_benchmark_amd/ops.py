@@ -656,7 +656,7 @@ def concat_channels(parts: Sequence[torch.Tensor]) -> torch.Tensor:
     p0 = parts[0]
     b, h, w = p0.shape[0], p0.shape[2], p0.shape[3]
     plane = h * w
-    ok = 1 <= len(parts) <= 8 and plane % 4 == 0 and b <= 65535
+    ok = 2 <= len(parts) <= 8 and plane % 4 == 0 and b <= 65535        # (one part: torch's copy is one call with less host work)
     for t in parts:
         ok = ok and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.shape[0] == b and tuple(t.shape[2:]) == (h, w) \
             and t.stride(3) == 1 and t.stride(2) == w and t.stride(1) == plane and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
